@@ -1,0 +1,323 @@
+/*
+ * libmfcnet_hip.so -- C ABI of the MI355X-native MFCNet hot path (gfx950 only).
+ *
+ * The reference (shadowfax11/mfcnet-tracker) has NO native interface for this
+ * path: all of its arithmetic runs inside stock PyTorch/cuDNN operators called
+ * from models/hrnet.py and models/multiframe_model.py.  Each entry point below
+ * therefore cites the reference *operator call* it replaces; the only native
+ * precedent in the reference is the 8-function pybind surface of
+ * models/sync_bn/inplace_abn/src/inplace_abn.cpp:66-75 (mean_var / forward /
+ * edz_eydz / backward), whose MI355X equivalents are mfc_bn_finalize,
+ * mfc_combine_fwd, mfc_bnbwd_reduce/_finalize/_apply.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()); no torch types;
+ *   - activations are NHWC with a padded channel pitch Cp (multiple of 8);
+ *     element type T is float (MFC_F32, parity mode) or bf16 (MFC_BF16,
+ *     throughput mode); statistics, coefficients, parameters, parameter
+ *     gradients and optimizer state are always fp32;
+ *   - a "granule" is 16 bytes = 4 floats or 8 bf16 of one pixel;
+ *   - "groups": the T frames of a clip are batched as N = T*B images with
+ *     G = T statistic groups (images_per_group = B), because the reference runs
+ *     base_model once per frame with separate BatchNorm batches
+ *     (models/multiframe_model.py:459-461);
+ *   - functions return 0 on success, a negative mfc_status otherwise; they never
+ *     throw, never allocate, never synchronise; all work is enqueued on `stream`
+ *     (a hipStream_t; pass torch.cuda.current_stream().cuda_stream);
+ *   - re-entrant per stream, no hidden global state.
+ */
+#ifndef MFCNET_HIP_H
+#define MFCNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MFC_F32 = 0, MFC_BF16 = 1 } mfc_dtype;
+
+typedef enum {
+    MFC_OK = 0,
+    MFC_ERR_INVALID_ARG = -1,
+    MFC_ERR_UNSUPPORTED = -2,
+    MFC_ERR_LAUNCH = -3
+} mfc_status;
+
+#define MFC_STAT_REPLICAS 32   /* rows the per-channel sum atomics are spread over */
+
+/* ---- BatchNorm coefficient block: fp32 [G][4][Cp] = scale, shift, mean, rstd ---- */
+#define MFC_COEF_SCALE 0
+#define MFC_COEF_SHIFT 1
+#define MFC_COEF_MEAN  2
+#define MFC_COEF_RSTD  3
+
+/* ------------------------------------------------------------------------------------
+ * Convolution as an implicit GEMM on MFMA (forward, and data-gradient by re-use).
+ * Replaces: every nn.Conv2d call of models/hrnet.py (conv3x3 :39-42, Bottleneck 1x1 :82-88,
+ * fuse 1x1 / strided 3x3 :200-230, transition :361-386, last_layer :334-351) and of the
+ * temporal head models/multiframe_model.py:191-201 (11x11, 3x3, 1x1); in backward, the
+ * cuDNN dgrad those calls trigger under loss.backward() (src/engine.py:70).
+ *
+ * Logical problem: out[n, i, j, co] = sum_{a<TA, b<TB, ci} Wp[a,b][ci][co] *
+ *                     f(in[n, i*in_stride + dh0 + a, j*in_stride + dw0 + b, ci])
+ * where f is the optional fused input transform relu?(x*scale[g,ci] + shift[g,ci])
+ * (BatchNorm-apply of the producer layer; zero padding is applied AFTER f), and the
+ * logical output pixel (i,j), i<Hl, j<Wl is stored at tensor pixel
+ * (i*out_sh + out_oh, j*out_sw + out_ow) of out[N, Hout, Wout, Cout_p].
+ *   forward conv k,s,p :  TA=TB=k, dh0=dw0=-p, in_stride=s, out stride 1
+ *   dgrad of stride 1   :  flipped taps (done by the weight packer), dh0=-(k-1-p)
+ *   dgrad of stride 2   :  four launches, one per output parity class
+ * Wp is the packed weight image produced by mfc_pack_weights.
+ * Optional epilogue: + bias[co]; out = acc + out (accumulate); per-(group,channel)
+ * sum / sum-of-squares of the fp32 results added to out_stats[replica][G][2][Cs].
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* in;          /* T [N, Hin, Win, Cin_p] */
+    const void* wp;          /* T packed weights [TA*TB][Kg][Np16][granule] */
+    void* out;               /* T [N, Hout, Wout, Cout_p] */
+    const float* bias;       /* [>=Cout] or NULL */
+    const float* in_coef;    /* [G][4][Cin_p] or NULL (no input transform) */
+    float* out_stats;        /* [MFC_STAT_REPLICAS][G][2][Cout_p] or NULL */
+    int32_t dtype;
+    int32_t N, Hin, Win, Cin_p, Cin;       /* Cin = channels actually reduced over (<= Cin_p) */
+    int32_t Hout, Wout, Cout_p, Cout;      /* physical output tensor */
+    int32_t Hl, Wl;                        /* logical output grid of this launch */
+    int32_t TA, TB, dh0, dw0, in_stride;
+    int32_t out_sh, out_sw, out_oh, out_ow;
+    int32_t in_relu, images_per_group, accumulate;
+    int32_t TH, TW;                        /* pixel tile (TH*TW <= 128); 0 = choose */
+} mfc_conv_desc;
+int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream);
+/* LDS bytes a launch of `d` needs (for tests / planners); <0 on invalid desc. */
+int mfc_conv2d_lds_bytes(const mfc_conv_desc* d);
+
+/* ------------------------------------------------------------------------------------
+ * Weight packer: fp32 reference layout [Cout][Cin][KH][KW] (nn.Conv2d.weight, the
+ * state_dict layout of SURVEY.md 3.4) -> the packed image(s) the conv kernel reads.
+ * One launch handles a whole table of jobs (all ~311 convolutions of the net).
+ *   mode 0: forward image          n = cout, k = cin, tap(a,b) = (kh0 + a*kh_step, kw0 + b*kw_step)
+ *   mode 1: data-gradient image    n = cin,  k = cout (roles swapped), same tap rule
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t src;            /* const float* [Cout][Cin][KH][KW] */
+    uint64_t dst;            /* T* [TA*TB][Kg][Np][granule] */
+    int32_t Cout, Cin, KH, KW;
+    int32_t TA, TB, kh0, kh_step, kw0, kw_step;
+    int32_t mode;            /* 0 fwd, 1 dgrad */
+    int32_t Kg, Np;          /* granules along k, padded n (multiple of 16) */
+    int32_t block0;          /* first block of this job in the launch (prefix sum) */
+    int32_t nblocks;
+    int32_t pad_;
+} mfc_pack_job;
+int mfc_pack_weights(const mfc_pack_job* jobs_dev, int32_t njobs, int32_t total_blocks, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight gradient.  Replaces the cuDNN wgrad of every conv above under loss.backward().
+ *   dWp[a,b][co][ci] += sum_{n,i,j} dy[n,i,j,co] * f(x[n, i*s+dh0+a, j*s+dw0+b, ci])
+ * accumulated with fp32 atomics into a packed image [TA*TB][Cout16][Cin16] that must be
+ * zero at step start; mfc_unpack_wgrad converts all images to the reference layout.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* x;           /* T [N, Hin, Win, Cin_p] conv input (pre input-transform) */
+    const void* dy;          /* T [N, Hout, Wout, Cout_p] */
+    float* dwp;              /* fp32 [TA*TB][Co16][Ci16] */
+    const float* in_coef;    /* as in mfc_conv_desc */
+    int32_t dtype;
+    int32_t N, Hin, Win, Cin_p, Cin;
+    int32_t Hout, Wout, Cout_p, Cout;
+    int32_t TA, TB, dh0, dw0, in_stride;
+    int32_t in_relu, images_per_group;
+    int32_t TH, TW;
+    int32_t splits;          /* pixel splits (grid.x); 0 = choose */
+} mfc_wgrad_desc;
+int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream);
+
+typedef struct {
+    uint64_t src;            /* const float* packed [TA*TB][Co16][Ci16] */
+    uint64_t dst;            /* float* [Cout][Cin][KH][KW] gradient (overwritten) */
+    int32_t Cout, Cin, KH, KW, Co16, Ci16;
+    int32_t block0, nblocks;
+} mfc_unpack_job;
+int mfc_unpack_wgrad(const mfc_unpack_job* jobs_dev, int32_t njobs, int32_t total_blocks, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm statistics -> coefficients.  Replaces the statistics half of every
+ * nn.SyncBatchNorm / nn.BatchNorm2d call (hrnet.py:31, bn_helper.py:10,
+ * multiframe_model.py:193-199; kernel precedent inplace_abn_cuda.cu:76-111 mean_var).
+ * training=1: batch mean / biased var from the sums the conv epilogue accumulated, per
+ * group; running stats updated group after group with momentum 0.1 and unbiased var,
+ * num_batches_tracked += G.  training=0: coefficients from the running stats.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* stats;      /* [R][G][2][Cp] (training) */
+    float* coef;             /* out [G][4][Cp] */
+    const float* gamma;      /* [C] */
+    const float* beta;       /* [C] */
+    float* running_mean;     /* [C] */
+    float* running_var;      /* [C] */
+    int64_t* num_batches_tracked; /* scalar or NULL */
+    int32_t C, Cp, G, training;
+    float count;             /* elements per (group, channel) */
+    float eps, momentum;
+} mfc_bnfin_desc;
+int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Tensor views used by the element-wise kernels.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t ptr;            /* T* base of [N, H, W, Cp] */
+    uint64_t coef;           /* const float* [G][4][Cp_coef] BN coefficients or 0 */
+    int32_t H, W, Cp, c_off; /* c_off: first channel of the slice used (multiple of 8) */
+} mfc_view;
+
+/* out[:, :, :, slice] = relu?( sum_k  affine_k?( bilinear_k?( src_k ) ) )
+ * Replaces the BN-apply / ReLU / residual add / fuse-layer sum / F.interpolate element-wise
+ * tail: hrnet.py:62-63,66,71-72 (BasicBlock), :99-113 (Bottleneck), :245-260 (fuse sum with
+ * bilinear up-sampling, align_corners=False), :464-469 (4-way up-sample + concat).      */
+typedef struct {
+    mfc_view out;
+    mfc_view src[4];
+    int32_t nsrc, relu, dtype;
+    int32_t N, C;            /* C: channels in the slice (multiple of granule size or padded) */
+    int32_t images_per_group;
+} mfc_combine_desc;
+int mfc_combine_fwd(const mfc_combine_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm / ReLU backward (precedent: inplace_abn_cuda.cu:174-292 edz_eydz + backward).
+ *   m     = mask (mode 0: 1; mode 1: mask_src > 0; mode 2: y*scale+shift > 0)
+ *   reduce:   bstats[r][g][0][c] += sum g*m ;  bstats[r][g][1][c] += sum g*m*yhat
+ *   finalize: c1 = mean(g*m), c2 = mean(g*m*yhat)  (0 in eval mode);
+ *             dgamma[c] = sum_g sum g*m*yhat, dbeta[c] = sum_g sum g*m
+ *   apply:    dy = scale * (g*m - c1 - yhat*c2)
+ * `g` may be a bilinear-up-sampled view's gradient already reduced to y's resolution.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    mfc_view g;              /* gradient wrt the BN output (post-activation if mask) */
+    mfc_view y;              /* conv output (pre-BN); y.coef = this BN's coefficient block */
+    mfc_view mask;           /* mode 1: tensor whose sign gives the ReLU mask */
+    mfc_view dy;             /* apply: destination (may alias g) */
+    float* bstats;           /* [R][G][2][Cp] */
+    const float* bcoef;      /* [G][2][Cp] c1, c2 (apply) */
+    int32_t mask_mode, dtype, N, C, images_per_group, accumulate;
+} mfc_bnbwd_desc;
+int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream);
+int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream);
+
+typedef struct {
+    const float* bstats;     /* [R][G][2][Cp] */
+    float* bcoef;            /* out [G][2][Cp] */
+    float* dgamma;           /* [C] (overwritten) */
+    float* dbeta;            /* [C] (overwritten) */
+    int32_t C, Cp, G, training;
+    float count;
+} mfc_bnbwdfin_desc;
+int mfc_bnbwd_finalize(const mfc_bnbwdfin_desc* d, void* stream);
+
+/* dst = (accumulate ? dst : 0) + adjoint_bilinear?( g * m )   -- gradient of identity /
+ * up-sampled terms of a combine (residual adds hrnet.py:71,112; fuse sums :250-259).      */
+typedef struct {
+    mfc_view g;              /* high-resolution gradient */
+    mfc_view mask;           /* same resolution as g (mode 1) */
+    mfc_view dst;            /* resolution of the term's source */
+    int32_t mask_mode, dtype, N, C, accumulate;
+} mfc_maskadd_desc;
+int mfc_mask_add(const mfc_maskadd_desc* d, void* stream);
+
+/* per-channel sum over pixels of dy (bias gradient of last_layer.0 / last_layer.3, hrnet.py:335-350) */
+int mfc_bias_grad(const void* dy, float* db, int32_t dtype, int64_t npix, int32_t Cp, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Layout bridges at the boundary (the reference API is NCHW fp32 lists of tensors,
+ * multiframe_model.py:457-471).
+ * ------------------------------------------------------------------------------------ */
+/* dst[n, h, w, c_off + c] = src[n, c, h, w], c < C; other channels of the granules touched are zeroed
+ * when zero_pad != 0 */
+int mfc_nchw_to_nhwc(const float* src, void* dst, int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                     int32_t Cp, int32_t c_off, int32_t zero_pad, void* stream);
+int mfc_nhwc_to_nchw(const void* src, float* dst, int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                     int32_t Cp, void* stream);
+
+/* Head input gather = x4 bilinear up-sampling of the T per-frame logit maps (hrnet.py:473-474)
+ * + channel concat with optical flow and depth (multiframe_model.py:462-469), optionally with the
+ * MultiFrameNetBasic flow warp (multiframe_model.py:89-170, incl. the 576x720 grid quirk).
+ *   xh[b, h, w, t*nc + k] = up4(logits[t*B + b])[h, w, k]      (warped by flow_{t-1} if warp)
+ *   then 2(T-1) flow channels (Large only) and T depth channels (warped if warp).          */
+typedef struct {
+    const void* logits;      /* T [T*B, Hs, Ws, Lp] */
+    const float* flow[8];    /* T-1 NCHW fp32 [B,2,H,W] or all NULL */
+    const float* depth[8];   /* T NCHW fp32 [B,1,H,W] or all NULL */
+    void* xh;                /* T [B, H, W, Cp] */
+    int32_t dtype, B, T, nc, Hs, Ws, Lp, H, W, Cp;
+    int32_t warp;            /* 1: MultiFrameNetBasic warp (flow consumed, not concatenated) */
+} mfc_headgather_desc;
+int mfc_head_gather_fwd(const mfc_headgather_desc* d, void* stream);
+/* dlogits[t*B+b] (overwritten) = adjoint of the above wrt logits; `xh` is d(xh). */
+int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Loss: F.log_softmax(dim=1) + class-weighted NLL + soft-Jaccard, forward and gradient
+ * wrt logits (src/engine.py:65-66, src/loss.py:31-63).  acc: fp32[16] zeroed by the call:
+ *   [0] sum w_t*(-logp_t)  [1] sum w_t   [2+c] I_c  [7+c] sum p_c  [12+c]... see loss.hip
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* logits;     /* NCHW fp32 [B, nc, H, W] */
+    const int64_t* target;   /* [B, H, W] */
+    const float* class_w;    /* [nc] */
+    float* acc;              /* fp32 [32] workspace / result block */
+    float* dlogits;          /* NCHW fp32 [B, nc, H, W] (bwd) */
+    int32_t B, nc, H, W;
+    float w_nll, w_jac, grad_scale;
+} mfc_loss_desc;
+int mfc_loss_fwd(const mfc_loss_desc* d, void* stream);   /* acc[16..19] = nll, jaccard, total */
+int mfc_loss_bwd(const mfc_loss_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Adam over flat fp32 arenas (torch.optim.Adam semantics, no weight decay, no amsgrad;
+ * scripts/train_multiframe_detection.py:128-151 uses two lr groups = two segments).
+ * ------------------------------------------------------------------------------------ */
+int mfc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int32_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Program interpreter: runs a whole forward or backward pass (hundreds of the calls above)
+ * from ONE host call, so the step is not bound by Python launch overhead and can be captured
+ * in a hipGraph.  Each record is {kind, payload}; payload is the matching *_desc.
+ * ------------------------------------------------------------------------------------ */
+typedef enum {
+    MFC_OP_CONV = 1, MFC_OP_WGRAD = 2, MFC_OP_BNFIN = 3, MFC_OP_COMBINE = 4, MFC_OP_BNBWD_REDUCE = 5,
+    MFC_OP_BNBWD_FIN = 6, MFC_OP_BNBWD_APPLY = 7, MFC_OP_MASK_ADD = 8, MFC_OP_HEAD_FWD = 9, MFC_OP_HEAD_BWD = 10,
+    MFC_OP_BIAS_GRAD = 11, MFC_OP_MEMSET = 12, MFC_OP_PACK = 13, MFC_OP_UNPACK = 14, MFC_OP_NCHW2NHWC = 15,
+    MFC_OP_NHWC2NCHW = 16
+} mfc_op_kind;
+
+typedef struct {
+    int32_t kind;
+    int32_t pad_;
+    union {
+        mfc_conv_desc conv;
+        mfc_wgrad_desc wgrad;
+        mfc_bnfin_desc bnfin;
+        mfc_combine_desc combine;
+        mfc_bnbwd_desc bnbwd;
+        mfc_bnbwdfin_desc bnbwdfin;
+        mfc_maskadd_desc maskadd;
+        mfc_headgather_desc head;
+        struct { mfc_headgather_desc d; uint64_t dlogits; } headbwd;
+        struct { uint64_t a, b, c; int64_t n; int32_t i[12]; } raw;   /* generic small ops */
+        uint8_t bytes[248];
+    } u;
+} mfc_op;
+/* runs ops[0..n); returns 0 or (-(1000*index) + status) of the first failing record */
+int mfc_program_run(const mfc_op* ops, int32_t n, void* stream);
+/* tuning switches: id 1 = use ds_read_b64_tr_b16 in the bf16 wgrad kernel (default 1) */
+int mfc_set_flag(int id, int value);
+int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
+const char* mfc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

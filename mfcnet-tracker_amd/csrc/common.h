@@ -1,0 +1,78 @@
+// Shared device helpers for libmfcnet_hip (gfx950 / CDNA4 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mfcnet_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define MFC_R MFC_STAT_REPLICAS
+
+// A granule = 16 bytes of one pixel's channels: 4 floats or 8 bf16.
+template <typename T> struct Gran;
+template <> struct Gran<float> {
+    static constexpr int E = 4;
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+        f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+__device__ inline unsigned bf16_bits(float f) {
+    bf16_t b = (bf16_t)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return (unsigned)__builtin_bit_cast(unsigned short, b);
+}
+template <> struct Gran<bf16_t> {
+    static constexpr int E = 8;
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(bf16_bits(f[0]) | (bf16_bits(f[1]) << 16), bf16_bits(f[2]) | (bf16_bits(f[3]) << 16),
+                          bf16_bits(f[4]) | (bf16_bits(f[5]) << 16), bf16_bits(f[6]) | (bf16_bits(f[7]) << 16));
+    }
+};
+
+template <typename T> __device__ inline float ld_elem(const T* p);
+template <> __device__ inline float ld_elem<float>(const float* p) { return *p; }
+template <> __device__ inline float ld_elem<bf16_t>(const bf16_t* p) { return (float)*p; }
+template <typename T> __device__ inline void st_elem(T* p, float v);
+template <> __device__ inline void st_elem<float>(float* p, float v) { *p = v; }
+template <> __device__ inline void st_elem<bf16_t>(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
+// logical ids so neighbouring tiles (shared halos / shared input patch across cout blocks)
+// hit the same L2.  Bijective for any nwg (guide T1).  Speed only, never correctness.
+__device__ inline int xcd_remap(int bid, int nwg) {
+    int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+__device__ inline float wave16_sum(float v) {      // sum over the 16 lanes sharing lane>>4
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    return v;
+}
+
+// bilinear source index / weight, align_corners=False, explicit output size
+// (ATen area_pixel_compute_source_index: scale = in/out, src = scale*(dst+0.5)-0.5 clamped at 0)
+__device__ inline void bilin_src(int dst, int in_size, int out_size, int& i0, int& i1, float& lam) {
+    float scale = (float)in_size / (float)out_size;
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    lam = s - (float)i0;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+#define MFC_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return MFC_ERR_LAUNCH; } while (0)

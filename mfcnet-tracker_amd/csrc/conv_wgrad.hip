@@ -1,0 +1,283 @@
+// Weight-gradient convolution on MFMA for gfx950.
+//   dWp[a,b][co][ci] += sum_{n,i,j} dy[n,i,j,co] * f(x[n, i*s+dh0+a, j*s+dw0+b, ci])
+// GEMM view: M = cout, N = cin, K = pixels.  A workgroup owns one tap row `a`, a block of
+// NCO*16 couts and NCI*16 cins (TB*NCO*NCI accumulator tiles spread over its 4 waves) and walks
+// a strided set of 128-pixel tiles, staging the dy tile and the matching input rows in LDS (with
+// the producer's BN-apply + ReLU fused into the staging pass, exactly as the forward kernel sees
+// the input).  Both MFMA operands need the PIXEL axis packed in-lane while memory has channels
+// contiguous: bf16 uses ds_read_b64_tr_b16 (hardware transpose read), fp32 reads single dwords.
+// Partials are flushed once per workgroup with fp32 atomics into the packed image
+// [tap][Co16][Ci16] (64-byte contiguous segments), later unpacked by mfc_unpack_wgrad.
+// Replaces: the cuDNN wgrad triggered by loss.backward() (src/engine.py:70) for every nn.Conv2d
+// of models/hrnet.py and models/multiframe_model.py:191-201.
+#include "common.h"
+
+static int g_wgrad_use_tr = 1;
+extern "C" int mfc_set_flag(int id, int value) {
+    if (id == 1) { g_wgrad_use_tr = value; return 0; }
+    return MFC_ERR_INVALID_ARG;
+}
+
+struct WgradK {
+    const char* x; const char* dy; float* dwp; const float* in_coef;
+    int N, Hin, Win, Cin_p, Hout, Wout, Cout_p;
+    int TA, TB, dh0, dw0, s, in_relu, ipg;
+    int TH, TW, tilesY, tilesX, ntiles, splits;
+    int Co16, Ci16, NCO, NCI, co_blocks, ci_blocks;
+    int PW, pitch_d, pitch_x, off_x, off_tab;
+    int ntile_mm, cnt;      // accumulator tiles per block, per wave
+};
+
+template <typename T, int TPW, bool TR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
+    constexpr int E = Gran<T>::E;
+    constexpr bool BF = (E == 8);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ds = smem;
+    char* Xs = smem + p.off_x;
+    int* ptab = (int*)(smem + p.off_tab);        // [128] ty<<16|tx (or -1)
+    int* xoff = ptab + 128;                      // [128] patch byte offset of pixel (tap b = 0)
+    int* ttab = xoff + 128;                      // [4][TPW][4]: offA, offB, out index, valid
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int y = blockIdx.y;
+    const int ib = y % p.ci_blocks; y /= p.ci_blocks;
+    const int cb = y % p.co_blocks; const int a = y / p.co_blocks;
+    const int co0 = cb * p.NCO * 16, ci0 = ib * p.NCI * 16;
+
+    if (tid < 128) {
+        int ty = tid / p.TW, tx = tid - ty * p.TW;
+        bool v = tid < p.TH * p.TW;
+        ptab[tid] = v ? ((ty << 16) | tx) : -1;
+        xoff[tid] = v ? (ty * p.PW + tx * p.s) * p.pitch_x : 0;
+    }
+    for (int t = tid; t < 4 * TPW; t += 256) {
+        int w = t / TPW, i = t - w * TPW;
+        int tile = w * p.cnt + i;
+        bool v = (i < p.cnt) && (tile < p.ntile_mm);
+        int b = 0, cot = 0, cit = 0;
+        if (v) { cit = tile % p.NCI; int r = tile / p.NCI; cot = r % p.NCO; b = r / p.NCO; }
+        ttab[t * 4 + 0] = cot * 16 * (int)sizeof(T);
+        ttab[t * 4 + 1] = b * p.pitch_x + cit * 16 * (int)sizeof(T);
+        ttab[t * 4 + 2] = ((a * p.TB + b) * p.Co16 + co0 + cot * 16) * p.Ci16 + ci0 + cit * 16;
+        ttab[t * 4 + 3] = (v && co0 + cot * 16 < p.Co16 && ci0 + cit * 16 < p.Ci16) ? 1 : 0;
+    }
+
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int gd = p.NCO * 16 / E, gx = p.NCI * 16 / E;
+    int GDP = 1; while (GDP < gd) GDP <<= 1;
+    int GXP = 1; while (GXP < gx) GXP <<= 1;
+    const int npx = p.TH * p.PW;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += p.splits) {
+        int r = tile;
+        const int tx_i = r % p.tilesX; r /= p.tilesX;
+        const int ty_i = r % p.tilesY; const int n = r / p.tilesY;
+        const int i0 = ty_i * p.TH, j0 = tx_i * p.TW;
+        const int grp = n / p.ipg;
+        __syncthreads();                      // tables ready / previous tile consumed
+        {   // ---- dy tile -> Ds[pixel][co] ----
+            const int gi = tid & (GDP - 1);
+            const bool gok = gi < gd && (co0 + gi * E) < p.Cout_p;
+            if (gi < gd) {
+                for (int pp = tid / GDP; pp < 128; pp += 256 / GDP) {
+                    int tt = ptab[pp];
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (tt >= 0 && gok) {
+                        int oi = i0 + (tt >> 16), oj = j0 + (tt & 0xffff);
+                        if (oi < p.Hout && oj < p.Wout)
+                            v = *(const uint4*)(p.dy + ((((size_t)n * p.Hout + oi) * p.Wout + oj) * p.Cout_p + co0) * sizeof(T) + (size_t)gi * 16);
+                    }
+                    *(uint4*)(Ds + pp * p.pitch_d + gi * 16) = v;
+                }
+            }
+        }
+        {   // ---- input rows of tap row a -> Xs[ty][px][ci], fused BN-apply + ReLU ----
+            const int gi = tid & (GXP - 1);
+            const bool gok = gi < gx && (ci0 + gi * E) < p.Cin_p;
+            float sc[E], sh[E];
+            const bool xf = (p.in_coef != nullptr) && gok;
+            if (xf) {
+                const float* cf = p.in_coef + (size_t)grp * 4 * p.Cin_p + ci0 + gi * E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { sc[e] = cf[e]; sh[e] = cf[p.Cin_p + e]; }
+            }
+            if (gi < gx) {
+                for (int pix = tid / GXP; pix < npx; pix += 256 / GXP) {
+                    int ty = pix / p.PW, px = pix - ty * p.PW;
+                    int ih = (i0 + ty) * p.s + p.dh0 + a, iw = j0 * p.s + p.dw0 + px;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (gok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
+                        v = *(const uint4*)(p.x + ((((size_t)n * p.Hin + ih) * p.Win + iw) * p.Cin_p + ci0) * sizeof(T) + (size_t)gi * 16);
+                        if (xf) {
+                            float f[E];
+                            Gran<T>::unpack(v, f);
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                float t = f[e] * sc[e] + sh[e];
+                                f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
+                            }
+                            v = Gran<T>::pack(f);
+                        }
+                    }
+                    *(uint4*)(Xs + pix * p.pitch_x + gi * 16) = v;
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (BF) {
+#pragma unroll 1
+            for (int ks = 0; ks < 4; ++ks) {
+                if constexpr (TR) {
+                    const int pr0 = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2);
+                    const int csub = (lane & 3) * 8;            // 4 bf16 = 8 bytes
+                    const int dA0 = pr0 * p.pitch_d + csub, dA1 = (pr0 + 4) * p.pitch_d + csub;
+                    const int dB0 = xoff[pr0] + csub, dB1 = xoff[pr0 + 4] + csub;
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) {
+                        const int* tt = ttab + (wave * TPW + i) * 4;
+                        if (i < p.cnt) {
+                            const int oa = tt[0], ob = tt[1];
+                            typedef __attribute__((address_space(3))) s16x4 lds_s4;
+                            s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Ds + dA0 + oa));
+                            s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Ds + dA1 + oa));
+                            s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Xs + dB0 + ob));
+                            s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Xs + dB1 + ob));
+                            typedef __attribute__((ext_vector_type(8))) short s16x8;
+                            s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                            s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    const int pk = ks * 32 + 8 * (lane >> 4);
+                    const int cl = (lane & 15) * 2;
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) {
+                        const int* tt = ttab + (wave * TPW + i) * 4;
+                        if (i < p.cnt) {
+                            const int oa = tt[0], ob = tt[1];
+                            typedef __attribute__((ext_vector_type(8))) short s16x8;
+                            s16x8 av, bv;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                av[j] = *(const short*)(Ds + (pk + j) * p.pitch_d + oa + cl);
+                                bv[j] = *(const short*)(Xs + xoff[pk + j] + ob + cl);
+                            }
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int ks = 0; ks < 32; ++ks) {
+                const int pr = ks * 4 + (lane >> 4);
+                const int dA = pr * p.pitch_d + (lane & 15) * 4;
+                const int dB = xoff[pr] + (lane & 15) * 4;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int* tt = ttab + (wave * TPW + i) * 4;
+                    if (i < p.cnt) {
+                        float av = *(const float*)(Ds + dA + tt[0]);
+                        float bv = *(const float*)(Xs + dB + tt[1]);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- flush: D[row = co][col = ci]; lane holds col = lane&15, rows 4*(lane>>4)+r ----
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int* tt = ttab + (wave * TPW + i) * 4;
+        if (i < p.cnt && tt[3]) {
+            float* o = p.dwp + tt[2] + (size_t)((lane >> 4) * 4) * p.Ci16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(o + (size_t)r * p.Ci16, acc[i][r]);
+        }
+    }
+}
+
+void mfc_choose_tile_wg(int Hl, int Wl, int& TH, int& TW) {
+    double best = -1; int bh = 8, bw = 16;
+    for (int tw = 1; tw <= 128 && tw <= Wl; ++tw) {
+        int th = 128 / tw; if (th > Hl) th = Hl; if (th < 1) continue;
+        double tiles = (double)ceil_div(Hl, th) * ceil_div(Wl, tw);
+        double eff = (double)Hl * Wl / (tiles * 128.0);
+        double score = eff + ((tw % 16 == 0) ? 0.01 : 0.0) + 0.02 * (double)(th * tw) / ((th + 2.0) * (tw + 2.0));
+        if (score > best) { best = score; bh = th; bw = tw; }
+    }
+    TH = bh; TW = bw;
+}
+
+template <typename T, int TPW, bool TR>
+static int wgrad_launch(const WgradK& k, size_t lds, int Y, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, TPW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, TPW, TR>), dim3(k.splits, Y), dim3(256), lds, st, k);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+extern "C" int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream) {
+    if (!d || !d->x || !d->dy || !d->dwp) return MFC_ERR_INVALID_ARG;
+    if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
+    if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin > d->Cin_p || d->Cout > d->Cout_p) return MFC_ERR_INVALID_ARG;
+    if (d->N <= 0 || d->TA <= 0 || d->TB <= 0 || d->in_stride < 1 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
+    const int esz = d->dtype == MFC_BF16 ? 2 : 4;
+    WgradK k;
+    k.x = (const char*)d->x; k.dy = (const char*)d->dy; k.dwp = d->dwp; k.in_coef = d->in_coef;
+    k.N = d->N; k.Hin = d->Hin; k.Win = d->Win; k.Cin_p = d->Cin_p; k.Hout = d->Hout; k.Wout = d->Wout; k.Cout_p = d->Cout_p;
+    k.TA = d->TA; k.TB = d->TB; k.dh0 = d->dh0; k.dw0 = d->dw0; k.s = d->in_stride; k.in_relu = d->in_relu; k.ipg = d->images_per_group;
+    k.TH = d->TH; k.TW = d->TW;
+    if (k.TH <= 0 || k.TW <= 0) mfc_choose_tile_wg(d->Hout, d->Wout, k.TH, k.TW);
+    if (k.TH * k.TW > 128) return MFC_ERR_INVALID_ARG;
+    k.tilesY = ceil_div(d->Hout, k.TH); k.tilesX = ceil_div(d->Wout, k.TW);
+    k.ntiles = k.N * k.tilesY * k.tilesX;
+    k.Co16 = ceil_div(d->Cout, 16) * 16; k.Ci16 = ceil_div(d->Cin, 16) * 16;
+    const int co_t = k.Co16 / 16, ci_t = k.Ci16 / 16;
+    // accumulator budget: TB * NCO * NCI <= 112 tiles per workgroup (28 per wave)
+    int NCO = co_t < 6 ? co_t : 6, NCI = ci_t < 6 ? ci_t : 6;
+    while (k.TB * NCO * NCI > 112) { if (NCI >= NCO && NCI > 1) --NCI; else if (NCO > 1) --NCO; else return MFC_ERR_UNSUPPORTED; }
+    // even out the blocks
+    k.co_blocks = ceil_div(co_t, NCO); NCO = ceil_div(co_t, k.co_blocks);
+    k.ci_blocks = ceil_div(ci_t, NCI); NCI = ceil_div(ci_t, k.ci_blocks);
+    k.NCO = NCO; k.NCI = NCI;
+    k.ntile_mm = k.TB * NCO * NCI; k.cnt = ceil_div(k.ntile_mm, 4);
+    k.PW = (k.TW - 1) * k.s + k.TB;
+    k.pitch_d = NCO * 16 * esz + 16; k.pitch_x = NCI * 16 * esz + 16;
+    size_t ds = (size_t)128 * k.pitch_d, xs = (size_t)k.TH * k.PW * k.pitch_x;
+    k.off_x = (int)ds; k.off_tab = (int)(ds + xs);
+    const int TPW = k.cnt <= 8 ? 8 : (k.cnt <= 16 ? 16 : 28);
+    size_t lds = ds + xs + (size_t)(256 + 4 * TPW * 4) * 4;
+    if (lds > 160 * 1024) return MFC_ERR_UNSUPPORTED;
+    const int Y = k.TA * k.co_blocks * k.ci_blocks;
+    int S = d->splits;
+    if (S <= 0) { S = ceil_div(1024, Y); }
+    if (S > k.ntiles) S = k.ntiles;
+    if (S < 1) S = 1;
+    k.splits = S;
+    hipStream_t st = (hipStream_t)stream;
+    const bool tr = g_wgrad_use_tr != 0;
+    if (d->dtype == MFC_BF16) {
+        if (tr) {
+            if (TPW == 8) return wgrad_launch<bf16_t, 8, true>(k, lds, Y, st);
+            if (TPW == 16) return wgrad_launch<bf16_t, 16, true>(k, lds, Y, st);
+            return wgrad_launch<bf16_t, 28, true>(k, lds, Y, st);
+        }
+        if (TPW == 8) return wgrad_launch<bf16_t, 8, false>(k, lds, Y, st);
+        if (TPW == 16) return wgrad_launch<bf16_t, 16, false>(k, lds, Y, st);
+        return wgrad_launch<bf16_t, 28, false>(k, lds, Y, st);
+    }
+    if (TPW == 8) return wgrad_launch<float, 8, false>(k, lds, Y, st);
+    if (TPW == 16) return wgrad_launch<float, 16, false>(k, lds, Y, st);
+    return wgrad_launch<float, 28, false>(k, lds, Y, st);
+}

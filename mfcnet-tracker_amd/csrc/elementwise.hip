@@ -1,0 +1,631 @@
+// HBM-bound element-wise / reduction kernels of the MFCNet hot path (gfx950).
+// All tensors NHWC with 16-byte granules; one thread moves one granule (coalesced 16-B accesses).
+//   mfc_bn_finalize      statistics -> BatchNorm coefficients + running-stat update
+//   mfc_combine_fwd      relu?(sum_k affine_k?(bilinear_k?(src_k)))      (BN-apply/ReLU/residual/fuse/up-sample)
+//   mfc_bnbwd_*          BatchNorm+ReLU backward: reduce / finalize / apply
+//   mfc_mask_add         gradient of identity / up-sampled combine terms (adjoint bilinear gather)
+//   mfc_bias_grad        per-channel sum
+//   layout bridges, head gather (x4 up-sample + temporal concat [+ flow warp]) forward/backward
+// Reference operators replaced: see include/mfcnet_hip.h.
+#include "common.h"
+
+// ------------------------------------------------------------------ BN finalize
+__global__ __launch_bounds__(256) void bn_finalize_kernel(mfc_bnfin_desc d) {
+    for (int c = threadIdx.x; c < d.Cp; c += 256) {
+        if (c >= d.C) {
+            for (int g = 0; g < d.G; ++g)
+                for (int k = 0; k < 4; ++k) d.coef[((size_t)g * 4 + k) * d.Cp + c] = 0.f;
+            continue;
+        }
+        const float gamma = d.gamma[c], beta = d.beta[c];
+        if (d.training) {
+            float rm = d.running_mean[c], rv = d.running_var[c];
+            for (int g = 0; g < d.G; ++g) {
+                double s = 0.0, s2 = 0.0;
+                for (int r = 0; r < MFC_R; ++r) {
+                    s += (double)d.stats[(((size_t)r * d.G + g) * 2 + 0) * d.Cp + c];
+                    s2 += (double)d.stats[(((size_t)r * d.G + g) * 2 + 1) * d.Cp + c];
+                }
+                const double mean = s / (double)d.count;
+                double var = s2 / (double)d.count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)d.eps));
+                const float scale = gamma * rstd;
+                d.coef[((size_t)g * 4 + MFC_COEF_SCALE) * d.Cp + c] = scale;
+                d.coef[((size_t)g * 4 + MFC_COEF_SHIFT) * d.Cp + c] = beta - (float)mean * scale;
+                d.coef[((size_t)g * 4 + MFC_COEF_MEAN) * d.Cp + c] = (float)mean;
+                d.coef[((size_t)g * 4 + MFC_COEF_RSTD) * d.Cp + c] = rstd;
+                const double unb = d.count > 1.f ? var * (double)d.count / ((double)d.count - 1.0) : var;
+                rm = (1.f - d.momentum) * rm + d.momentum * (float)mean;
+                rv = (1.f - d.momentum) * rv + d.momentum * (float)unb;
+            }
+            d.running_mean[c] = rm; d.running_var[c] = rv;
+        } else {
+            const float mean = d.running_mean[c];
+            const float rstd = 1.0f / sqrtf(d.running_var[c] + d.eps);
+            const float scale = gamma * rstd;
+            for (int g = 0; g < d.G; ++g) {
+                d.coef[((size_t)g * 4 + MFC_COEF_SCALE) * d.Cp + c] = scale;
+                d.coef[((size_t)g * 4 + MFC_COEF_SHIFT) * d.Cp + c] = beta - mean * scale;
+                d.coef[((size_t)g * 4 + MFC_COEF_MEAN) * d.Cp + c] = mean;
+                d.coef[((size_t)g * 4 + MFC_COEF_RSTD) * d.Cp + c] = rstd;
+            }
+        }
+    }
+    if (d.training && d.num_batches_tracked && threadIdx.x == 0) *d.num_batches_tracked += d.G;
+}
+
+extern "C" int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream) {
+    if (!d || !d->coef || !d->gamma || !d->beta || !d->running_mean || !d->running_var) return MFC_ERR_INVALID_ARG;
+    if (d->training && !d->stats) return MFC_ERR_INVALID_ARG;
+    if (d->C <= 0 || d->C > d->Cp || d->G <= 0) return MFC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// ------------------------------------------------------------------ combine forward
+template <typename T>
+__device__ inline void load_gran_f(const mfc_view& v, int n, int h, int w, int ch, float* f) {
+    const uint4 u = *(const uint4*)((const char*)v.ptr + ((((size_t)n * v.H + h) * v.W + w) * v.Cp + ch) * sizeof(T));
+    Gran<T>::unpack(u, f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, long total, int Cg) {
+    constexpr int E = Gran<T>::E;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % Cg); long pix = idx / Cg;
+    const int w = (int)(pix % d.out.W); pix /= d.out.W;
+    const int h = (int)(pix % d.out.H); const int n = (int)(pix / d.out.H);
+    const int grp = n / d.images_per_group;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < d.nsrc; ++k) {
+        const mfc_view& s = d.src[k];
+        const int ch = s.c_off + g * E;
+        float f[E];
+        if (s.H == d.out.H && s.W == d.out.W) {
+            load_gran_f<T>(s, n, h, w, ch, f);
+        } else {
+            int h0, h1, w0, w1; float lh, lw;
+            bilin_src(h, s.H, d.out.H, h0, h1, lh);
+            bilin_src(w, s.W, d.out.W, w0, w1, lw);
+            float a[E], b[E], c[E], e4[E];
+            load_gran_f<T>(s, n, h0, w0, ch, a); load_gran_f<T>(s, n, h0, w1, ch, b);
+            load_gran_f<T>(s, n, h1, w0, ch, c); load_gran_f<T>(s, n, h1, w1, ch, e4);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                f[e] = (1.f - lh) * ((1.f - lw) * a[e] + lw * b[e]) + lh * ((1.f - lw) * c[e] + lw * e4[e]);
+        }
+        if (s.coef) {
+            const float* cf = (const float*)s.coef + (size_t)grp * 4 * s.Cp + ch;
+#pragma unroll
+            for (int e = 0; e < E; ++e) f[e] = f[e] * cf[e] + cf[s.Cp + e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += f[e];
+    }
+    if (d.relu) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    }
+    *(uint4*)((char*)d.out.ptr + ((((size_t)n * d.out.H + h) * d.out.W + w) * d.out.Cp + d.out.c_off + g * E) * sizeof(T)) = Gran<T>::pack(acc);
+}
+
+static bool view_ok(const mfc_view& v, int E) { return v.ptr && v.H > 0 && v.W > 0 && v.Cp % 8 == 0 && v.c_off % E == 0; }
+
+extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
+    if (!d || d->nsrc < 1 || d->nsrc > 4) return MFC_ERR_INVALID_ARG;
+    const int E = d->dtype == MFC_BF16 ? 8 : 4;
+    if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
+    if (!view_ok(d->out, E) || d->C <= 0 || d->C % E || d->N <= 0 || d->images_per_group <= 0) return MFC_ERR_INVALID_ARG;
+    if (d->out.c_off + d->C > d->out.Cp) return MFC_ERR_INVALID_ARG;
+    for (int k = 0; k < d->nsrc; ++k)
+        if (!view_ok(d->src[k], E) || d->src[k].c_off + d->C > d->src[k].Cp) return MFC_ERR_INVALID_ARG;
+    const int Cg = d->C / E;
+    const long total = (long)d->N * d->out.H * d->out.W * Cg;
+    const int blocks = (int)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(combine_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    else hipLaunchKernelGGL(combine_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// ------------------------------------------------------------------ BN backward
+// mask value for a granule: mode 0 -> 1, mode 1 -> mask_src > 0, mode 2 -> y*scale+shift > 0
+template <typename T>
+__device__ inline void masked_grad(const mfc_bnbwd_desc& d, int n, int h, int w, int g, int grp, const float* yv, float* gm) {
+    constexpr int E = Gran<T>::E;
+    load_gran_f<T>(d.g, n, h, w, d.g.c_off + g * E, gm);
+    if (d.mask_mode == 1) {
+        float m[E];
+        load_gran_f<T>(d.mask, n, h, w, d.mask.c_off + g * E, m);
+#pragma unroll
+        for (int e = 0; e < E; ++e) gm[e] = m[e] > 0.f ? gm[e] : 0.f;
+    } else if (d.mask_mode == 2) {
+        const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + d.y.c_off + g * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) gm[e] = (yv[e] * cf[e] + cf[d.y.Cp + e]) > 0.f ? gm[e] : 0.f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int Cg, int PPI, int pix_per_block, long pix_per_group) {
+    constexpr int E = Gran<T>::E;
+    __shared__ float red[256 * 8 * 2];
+    const int grp = blockIdx.y;
+    const int gi = threadIdx.x % Cg, prow = threadIdx.x / Cg;
+    float s1[E], s2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + d.y.c_off + gi * E;
+    float mean[E], rstd[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { mean[e] = cf[2 * d.y.Cp + e]; rstd[e] = cf[3 * d.y.Cp + e]; }
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    long p1 = p0 + pix_per_block; if (p1 > pix_per_group) p1 = pix_per_group;
+    const long HW = (long)d.y.H * d.y.W;
+    for (long pp = p0 + prow; pp < p1; pp += PPI) {
+        const long gp = (long)grp * pix_per_group + pp;
+        const int n = (int)(gp / HW); const long r = gp - (long)n * HW;
+        const int h = (int)(r / d.y.W), w = (int)(r - (long)h * d.y.W);
+        float yv[E], gm[E];
+        load_gran_f<T>(d.y, n, h, w, d.y.c_off + gi * E, yv);
+        masked_grad<T>(d, n, h, w, gi, grp, yv, gm);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { s1[e] += gm[e]; s2[e] += gm[e] * (yv[e] - mean[e]) * rstd[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) { red[(threadIdx.x * E + e) * 2] = s1[e]; red[(threadIdx.x * E + e) * 2 + 1] = s2[e]; }
+    __syncthreads();
+    if (prow == 0) {
+        const int rep = blockIdx.x % MFC_R;
+        const int G = gridDim.y;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float a = 0.f, b = 0.f;
+            for (int q = 0; q < PPI; ++q) { a += red[((q * Cg + gi) * E + e) * 2]; b += red[((q * Cg + gi) * E + e) * 2 + 1]; }
+            const int c = d.y.c_off + gi * E + e;
+            atomicAdd(d.bstats + (((size_t)rep * G + grp) * 2 + 0) * d.y.Cp + c, a);
+            atomicAdd(d.bstats + (((size_t)rep * G + grp) * 2 + 1) * d.y.Cp + c, b);
+        }
+    }
+}
+
+static int bnbwd_check(const mfc_bnbwd_desc* d, int& E) {
+    if (!d || (d->dtype != MFC_F32 && d->dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
+    E = d->dtype == MFC_BF16 ? 8 : 4;
+    if (!view_ok(d->g, E) || !view_ok(d->y, E) || !d->y.coef || d->C <= 0 || d->C % E) return MFC_ERR_INVALID_ARG;
+    if (d->g.H != d->y.H || d->g.W != d->y.W) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode == 1 && (!view_ok(d->mask, E) || d->mask.H != d->y.H || d->mask.W != d->y.W)) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode < 0 || d->mask_mode > 2) return MFC_ERR_INVALID_ARG;
+    if (d->N <= 0 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
+    return MFC_OK;
+}
+
+extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
+    int E; int rc = bnbwd_check(d, E); if (rc < 0) return rc;
+    if (!d->bstats) return MFC_ERR_INVALID_ARG;
+    const int Cg = d->C / E;
+    if (Cg > 256) return MFC_ERR_UNSUPPORTED;
+    const int PPI = 256 / Cg;
+    const int G = d->N / d->images_per_group;
+    const long ppg = (long)d->images_per_group * d->y.H * d->y.W;
+    long want = ppg / 1024 + 1; if (want > 1024) want = 1024;       // blocks per group
+    int ppb = (int)((ppg + want - 1) / want);
+    ppb = ((ppb + PPI - 1) / PPI) * PPI;
+    const int bx = (int)((ppg + ppb - 1) / ppb);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_reduce_kernel<bf16_t>, dim3(bx, G), dim3(Cg * PPI), 0, st, *d, Cg, PPI, ppb, ppg);
+    else hipLaunchKernelGGL(bnbwd_reduce_kernel<float>, dim3(bx, G), dim3(Cg * PPI), 0, st, *d, Cg, PPI, ppb, ppg);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+__global__ __launch_bounds__(256) void bnbwd_finalize_kernel(mfc_bnbwdfin_desc d) {
+    for (int c = threadIdx.x; c < d.Cp; c += 256) {
+        double dg = 0.0, db = 0.0;
+        for (int g = 0; g < d.G; ++g) {
+            double s1 = 0.0, s2 = 0.0;
+            if (c < d.C)
+                for (int r = 0; r < MFC_R; ++r) {
+                    s1 += (double)d.bstats[(((size_t)r * d.G + g) * 2 + 0) * d.Cp + c];
+                    s2 += (double)d.bstats[(((size_t)r * d.G + g) * 2 + 1) * d.Cp + c];
+                }
+            d.bcoef[((size_t)g * 2 + 0) * d.Cp + c] = d.training ? (float)(s1 / (double)d.count) : 0.f;
+            d.bcoef[((size_t)g * 2 + 1) * d.Cp + c] = d.training ? (float)(s2 / (double)d.count) : 0.f;
+            db += s1; dg += s2;
+        }
+        if (c < d.C) { d.dgamma[c] = (float)dg; d.dbeta[c] = (float)db; }
+    }
+}
+
+extern "C" int mfc_bnbwd_finalize(const mfc_bnbwdfin_desc* d, void* stream) {
+    if (!d || !d->bstats || !d->bcoef || !d->dgamma || !d->dbeta || d->C <= 0 || d->C > d->Cp || d->G <= 0) return MFC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long total, int Cg) {
+    constexpr int E = Gran<T>::E;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % Cg); long pix = idx / Cg;
+    const int w = (int)(pix % d.y.W); pix /= d.y.W;
+    const int h = (int)(pix % d.y.H); const int n = (int)(pix / d.y.H);
+    const int grp = n / d.images_per_group;
+    float yv[E], gm[E], o[E];
+    load_gran_f<T>(d.y, n, h, w, d.y.c_off + g * E, yv);
+    masked_grad<T>(d, n, h, w, g, grp, yv, gm);
+    const int c = d.y.c_off + g * E;
+    const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + c;
+    const float* bc = d.bcoef + (size_t)grp * 2 * d.y.Cp + c;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const float yh = (yv[e] - cf[2 * d.y.Cp + e]) * cf[3 * d.y.Cp + e];
+        o[e] = cf[e] * (gm[e] - bc[e] - yh * bc[d.y.Cp + e]);
+    }
+    *(uint4*)((char*)d.dy.ptr + ((((size_t)n * d.dy.H + h) * d.dy.W + w) * d.dy.Cp + d.dy.c_off + g * E) * sizeof(T)) = Gran<T>::pack(o);
+}
+
+extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
+    int E; int rc = bnbwd_check(d, E); if (rc < 0) return rc;
+    if (!d->bcoef || !view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W) return MFC_ERR_INVALID_ARG;
+    const int Cg = d->C / E;
+    const long total = (long)d->N * d->y.H * d->y.W * Cg;
+    const int blocks = (int)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    else hipLaunchKernelGGL(bnbwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// ------------------------------------------------------------------ mask_add (+ adjoint bilinear)
+// candidate high-res index range whose bilinear footprint can touch low-res index `s`
+__device__ inline void adj_range(int s, int in_size, int out_size, int& lo, int& hi) {
+    const float f = (float)out_size / (float)in_size;
+    lo = (int)floorf(f * ((float)s - 0.5f) - 0.5f) - 1;
+    hi = (int)ceilf(f * ((float)s + 1.5f) - 0.5f) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out_size - 1) hi = out_size - 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mask_add_kernel(mfc_maskadd_desc d, long total, int Cg) {
+    constexpr int E = Gran<T>::E;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % Cg); long pix = idx / Cg;
+    const int w = (int)(pix % d.dst.W); pix /= d.dst.W;
+    const int h = (int)(pix % d.dst.H); const int n = (int)(pix / d.dst.H);
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    if (d.dst.H == d.g.H && d.dst.W == d.g.W) {
+        load_gran_f<T>(d.g, n, h, w, d.g.c_off + g * E, acc);
+        if (d.mask_mode == 1) {
+            float m[E];
+            load_gran_f<T>(d.mask, n, h, w, d.mask.c_off + g * E, m);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = m[e] > 0.f ? acc[e] : 0.f;
+        }
+    } else {
+        int hlo, hhi, wlo, whi;
+        adj_range(h, d.dst.H, d.g.H, hlo, hhi);
+        adj_range(w, d.dst.W, d.g.W, wlo, whi);
+        for (int hh = hlo; hh <= hhi; ++hh) {
+            int h0, h1; float lh;
+            bilin_src(hh, d.dst.H, d.g.H, h0, h1, lh);
+            float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+            if (wh == 0.f) continue;
+            for (int ww = wlo; ww <= whi; ++ww) {
+                int w0, w1; float lw;
+                bilin_src(ww, d.dst.W, d.g.W, w0, w1, lw);
+                float wt = wh * ((w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f));
+                if (wt == 0.f) continue;
+                float gv[E];
+                load_gran_f<T>(d.g, n, hh, ww, d.g.c_off + g * E, gv);
+                if (d.mask_mode == 1) {
+                    float m[E];
+                    load_gran_f<T>(d.mask, n, hh, ww, d.mask.c_off + g * E, m);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) gv[e] = m[e] > 0.f ? gv[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] += wt * gv[e];
+            }
+        }
+    }
+    char* o = (char*)d.dst.ptr + ((((size_t)n * d.dst.H + h) * d.dst.W + w) * d.dst.Cp + d.dst.c_off + g * E) * sizeof(T);
+    if (d.accumulate) {
+        float old[E];
+        Gran<T>::unpack(*(const uint4*)o, old);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += old[e];
+    }
+    *(uint4*)o = Gran<T>::pack(acc);
+}
+
+extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
+    if (!d || (d->dtype != MFC_F32 && d->dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
+    const int E = d->dtype == MFC_BF16 ? 8 : 4;
+    if (!view_ok(d->g, E) || !view_ok(d->dst, E) || d->C <= 0 || d->C % E || d->N <= 0) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode != 0 && d->mask_mode != 1) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode == 1 && (!view_ok(d->mask, E) || d->mask.H != d->g.H || d->mask.W != d->g.W)) return MFC_ERR_INVALID_ARG;
+    const int Cg = d->C / E;
+    const long total = (long)d->N * d->dst.H * d->dst.W * Cg;
+    const int blocks = (int)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(mask_add_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    else hipLaunchKernelGGL(mask_add_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// ------------------------------------------------------------------ bias gradient
+// db[c] += sum over pixels of dy[pix][c]   (db must be zero at step start)
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* dy, float* db, long npix, int Cp, int C, int CS, int pix_per_block) {
+    __shared__ float red[256];
+    const int cl = threadIdx.x % CS, prow = threadIdx.x / CS, PPI = blockDim.x / CS;
+    const int c = blockIdx.y * CS + cl;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    long p1 = p0 + pix_per_block; if (p1 > npix) p1 = npix;
+    float s = 0.f;
+    if (c < Cp)
+        for (long p = p0 + prow; p < p1; p += PPI) s += ld_elem<T>(dy + p * Cp + c);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (prow == 0 && c < C) {
+        float a = 0.f;
+        for (int q = 0; q < PPI; ++q) a += red[q * CS + cl];
+        atomicAdd(db + c, a);
+    }
+}
+
+extern "C" int mfc_bias_grad(const void* dy, float* db, int32_t dtype, int64_t npix, int32_t Cp, int32_t C, void* stream) {
+    if (!dy || !db || npix <= 0 || Cp <= 0 || C > Cp) return MFC_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nslab = (Cp + 255) / 256;
+    const int CS = (Cp + nslab - 1) / nslab;
+    const int PPI = 256 / CS;
+    long want = npix / 2048 + 1; if (want > 512) want = 512;
+    int ppb = (int)((npix + want - 1) / want);
+    const int blocks = (int)((npix + ppb - 1) / ppb);
+    if (dtype == MFC_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(blocks, nslab), dim3(CS * PPI), 0, st, (const bf16_t*)dy, db, (long)npix, Cp, C, CS, ppb);
+    else if (dtype == MFC_F32) hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks, nslab), dim3(CS * PPI), 0, st, (const float*)dy, db, (long)npix, Cp, C, CS, ppb);
+    else return MFC_ERR_INVALID_ARG;
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// ------------------------------------------------------------------ layout bridges
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* dst, int N, int C, int H, int W, int Cp, int c_off, long total) {
+    constexpr int E = Gran<T>::E;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one pixel per thread
+    if (idx >= total) return;
+    const long HW = (long)H * W;
+    const int n = (int)(idx / HW); const long r = idx - (long)n * HW;
+    const int ng = (C + E - 1) / E;
+    for (int g = 0; g < ng; ++g) {
+        float f[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = g * E + e;
+            f[e] = c < C ? src[((size_t)n * C + c) * HW + r] : 0.f;
+        }
+        *(uint4*)((char*)dst + ((size_t)idx * Cp + c_off + g * E) * sizeof(T)) = Gran<T>::pack(f);
+    }
+}
+
+extern "C" int mfc_nchw_to_nhwc(const float* src, void* dst, int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                int32_t Cp, int32_t c_off, int32_t zero_pad, void* stream) {
+    (void)zero_pad;
+    if (!src || !dst || N <= 0 || C <= 0 || Cp % 8) return MFC_ERR_INVALID_ARG;
+    const int E = dtype == MFC_BF16 ? 8 : 4;
+    if (c_off % E || c_off + ((C + E - 1) / E) * E > Cp) return MFC_ERR_INVALID_ARG;
+    const long total = (long)N * H * W;
+    const int blocks = (int)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, src, (bf16_t*)dst, N, C, H, W, Cp, c_off, total);
+    else if (dtype == MFC_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, N, C, H, W, Cp, c_off, total);
+    else return MFC_ERR_INVALID_ARG;
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* src, float* dst, int C, long HW, int Cp, long total) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one output element per thread
+    if (idx >= total) return;
+    const long r = idx % HW; long t = idx / HW;
+    const int c = (int)(t % C); const long n = t / C;
+    dst[idx] = ld_elem<T>(src + (n * HW + r) * Cp + c);
+}
+
+extern "C" int mfc_nhwc_to_nchw(const void* src, float* dst, int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                int32_t Cp, void* stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || C > Cp) return MFC_ERR_INVALID_ARG;
+    const long HW = (long)H * W, total = (long)N * C * HW;
+    const int blocks = (int)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, C, HW, Cp, total);
+    else if (dtype == MFC_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, dst, C, HW, Cp, total);
+    else return MFC_ERR_INVALID_ARG;
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// ------------------------------------------------------------------ head gather
+// up4(logits)[h, w, k] for one frame: bilinear from the low-res logit map (hrnet.py:473-474)
+template <typename T>
+__device__ inline float up_logit(const T* L, int Hs, int Ws, int Lp, int H, int W, int h, int w, int k) {
+    int h0, h1, w0, w1; float lh, lw;
+    bilin_src(h, Hs, H, h0, h1, lh);
+    bilin_src(w, Ws, W, w0, w1, lw);
+    const float a = ld_elem<T>(L + ((size_t)h0 * Ws + w0) * Lp + k), b = ld_elem<T>(L + ((size_t)h0 * Ws + w1) * Lp + k);
+    const float c = ld_elem<T>(L + ((size_t)h1 * Ws + w0) * Lp + k), e = ld_elem<T>(L + ((size_t)h1 * Ws + w1) * Lp + k);
+    return (1.f - lh) * ((1.f - lw) * a + lw * b) + lh * ((1.f - lw) * c + lw * e);
+}
+
+// grid_sample(bilinear, zeros, align_corners=True) sample position of output pixel (h, w) under the
+// MultiFrameNetBasic warp: grid normalised for 576x720 and cropped (multiframe_model.py:156-167,179-182)
+__device__ inline void warp_pos(int h, int w, int H, int W, float fx, float fy, float& x, float& y) {
+    const float gx = 2.0f * (float)w / 719.0f - 1.0f + fx / ((float)(W - 1) / 2.0f);
+    const float gy = 2.0f * (float)h / 575.0f - 1.0f + fy / ((float)(H - 1) / 2.0f);
+    x = (gx + 1.f) * 0.5f * (float)(W - 1);
+    y = (gy + 1.f) * 0.5f * (float)(H - 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_gather_fwd_kernel(mfc_headgather_desc d, long total) {
+    constexpr int E = Gran<T>::E;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one output pixel per thread
+    if (idx >= total) return;
+    const long HW = (long)d.H * d.W;
+    const int b = (int)(idx / HW); const long r = idx - (long)b * HW;
+    const int h = (int)(r / d.W), w = (int)(r - (long)h * d.W);
+    float v[40];
+    const int Cp = d.Cp;
+    for (int c = 0; c < Cp; ++c) v[c] = 0.f;
+    int c = 0;
+    for (int t = 0; t < d.T; ++t) {
+        const T* L = (const T*)d.logits + (size_t)(t * d.B + b) * d.Hs * d.Ws * d.Lp;
+        if (d.warp && t > 0) {
+            const float fx = d.flow[t - 1][((size_t)b * 2 + 0) * HW + r], fy = d.flow[t - 1][((size_t)b * 2 + 1) * HW + r];
+            float x, y; warp_pos(h, w, d.H, d.W, fx, fy, x, y);
+            const float xf = floorf(x), yf = floorf(y);
+            const int x0 = (int)xf, y0 = (int)yf;
+            const float ax = x - xf, ay = y - yf;
+            for (int k = 0; k < d.nc; ++k) {
+                float s = 0.f;
+                for (int dy_ = 0; dy_ < 2; ++dy_)
+                    for (int dx_ = 0; dx_ < 2; ++dx_) {
+                        const int yy = y0 + dy_, xx = x0 + dx_;
+                        if (yy < 0 || yy >= d.H || xx < 0 || xx >= d.W) continue;
+                        const float wt = (dy_ ? ay : 1.f - ay) * (dx_ ? ax : 1.f - ax);
+                        s += wt * up_logit<T>(L, d.Hs, d.Ws, d.Lp, d.H, d.W, yy, xx, k);
+                    }
+                v[c++] = s;
+            }
+        } else {
+            for (int k = 0; k < d.nc; ++k) v[c++] = up_logit<T>(L, d.Hs, d.Ws, d.Lp, d.H, d.W, h, w, k);
+        }
+    }
+    if (!d.warp && d.flow[0]) {
+        for (int t = 0; t < d.T - 1; ++t) {
+            v[c++] = d.flow[t][((size_t)b * 2 + 0) * HW + r];
+            v[c++] = d.flow[t][((size_t)b * 2 + 1) * HW + r];
+        }
+    }
+    if (d.depth[0]) {
+        for (int t = 0; t < d.T; ++t) {
+            if (d.warp && t > 0) {
+                const float fx = d.flow[t - 1][((size_t)b * 2 + 0) * HW + r], fy = d.flow[t - 1][((size_t)b * 2 + 1) * HW + r];
+                float x, y; warp_pos(h, w, d.H, d.W, fx, fy, x, y);
+                const float xf = floorf(x), yf = floorf(y);
+                const int x0 = (int)xf, y0 = (int)yf;
+                const float ax = x - xf, ay = y - yf;
+                float s = 0.f;
+                for (int dy_ = 0; dy_ < 2; ++dy_)
+                    for (int dx_ = 0; dx_ < 2; ++dx_) {
+                        const int yy = y0 + dy_, xx = x0 + dx_;
+                        if (yy < 0 || yy >= d.H || xx < 0 || xx >= d.W) continue;
+                        s += (dy_ ? ay : 1.f - ay) * (dx_ ? ax : 1.f - ax) * d.depth[t][(size_t)b * HW + (size_t)yy * d.W + xx];
+                    }
+                v[c++] = s;
+            } else {
+                v[c++] = d.depth[t][(size_t)b * HW + r];
+            }
+        }
+    }
+    for (int g = 0; g < Cp / E; ++g)
+        *(uint4*)((char*)d.xh + ((size_t)idx * Cp + g * E) * sizeof(T)) = Gran<T>::pack(v + g * E);
+}
+
+static int head_check(const mfc_headgather_desc* d) {
+    if (!d || !d->logits || !d->xh || (d->dtype != MFC_F32 && d->dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
+    if (d->T < 1 || d->T > 8 || d->nc < 1 || d->nc > d->Lp || d->Cp % 8 || d->Cp > 40 || d->Lp % 8) return MFC_ERR_INVALID_ARG;
+    int c = d->T * d->nc + ((!d->warp && d->flow[0]) ? 2 * (d->T - 1) : 0) + (d->depth[0] ? d->T : 0);
+    if (c > d->Cp) return MFC_ERR_INVALID_ARG;
+    if (d->warp && !d->flow[0]) return MFC_ERR_INVALID_ARG;
+    if (d->warp && (d->H > 576 || d->W > 720)) return MFC_ERR_UNSUPPORTED;   // reference raises here too (SURVEY A7 ii)
+    return MFC_OK;
+}
+
+extern "C" int mfc_head_gather_fwd(const mfc_headgather_desc* d, void* stream) {
+    int rc = head_check(d); if (rc < 0) return rc;
+    const long total = (long)d->B * d->H * d->W;
+    const int blocks = (int)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total);
+    else hipLaunchKernelGGL(head_gather_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// adjoint wrt the low-res logits.  No-warp: gather form.  Warp: the sample positions are data
+// dependent, so the adjoint is a scatter (fp32 atomics into a pre-zeroed fp32 scratch is avoided by
+// scattering straight into dlogits when T == float; bf16 uses the same kernel on an fp32 staging
+// buffer owned by the caller) -- only the gather form is built here; the warp adjoint scatters
+// with atomics into fp32 `dlogits` and therefore requires dtype == MFC_F32 staging.
+template <typename T>
+__global__ __launch_bounds__(256) void head_gather_bwd_kernel(mfc_headgather_desc d, T* dl, long total) {
+    constexpr int E = Gran<T>::E;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one low-res pixel of one (t, b) map
+    if (idx >= total) return;
+    const long HWs = (long)d.Hs * d.Ws;
+    const int tb = (int)(idx / HWs); const long r = idx - (long)tb * HWs;
+    const int hs = (int)(r / d.Ws), ws = (int)(r - (long)hs * d.Ws);
+    const int t = tb / d.B, b = tb - t * d.B;
+    float acc[8];
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    int hlo, hhi, wlo, whi;
+    adj_range(hs, d.Hs, d.H, hlo, hhi);
+    adj_range(ws, d.Ws, d.W, wlo, whi);
+    const T* G = (const T*)d.xh + (size_t)b * d.H * d.W * d.Cp + t * d.nc;
+    for (int hh = hlo; hh <= hhi; ++hh) {
+        int h0, h1; float lh;
+        bilin_src(hh, d.Hs, d.H, h0, h1, lh);
+        const float wh = (h0 == hs ? 1.f - lh : 0.f) + (h1 == hs ? lh : 0.f);
+        if (wh == 0.f) continue;
+        for (int ww = wlo; ww <= whi; ++ww) {
+            int w0, w1; float lw;
+            bilin_src(ww, d.Ws, d.W, w0, w1, lw);
+            const float wt = wh * ((w0 == ws ? 1.f - lw : 0.f) + (w1 == ws ? lw : 0.f));
+            if (wt == 0.f) continue;
+            const T* gp = G + ((size_t)hh * d.W + ww) * d.Cp;
+            for (int k = 0; k < d.nc; ++k) acc[k] += wt * ld_elem<T>(gp + k);
+        }
+    }
+    float o[8];
+    for (int k = 0; k < 8; ++k) o[k] = k < d.nc ? acc[k] : 0.f;
+    for (int g = 0; g < d.Lp / E; ++g) {
+        float z[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) z[e] = (g * E + e) < 8 ? o[g * E + e] : 0.f;
+        *(uint4*)((char*)dl + ((size_t)idx * d.Lp + g * E) * sizeof(T)) = Gran<T>::pack(z);
+    }
+}
+
+extern "C" int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, void* stream) {
+    int rc = head_check(d); if (rc < 0) return rc;
+    if (!dlogits || d->nc > 8) return MFC_ERR_INVALID_ARG;
+    if (d->warp) return MFC_ERR_UNSUPPORTED;
+    const long total = (long)d->T * d->B * d->Hs * d->Ws;
+    const int blocks = (int)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, (bf16_t*)dlogits, total);
+    else hipLaunchKernelGGL(head_gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, (float*)dlogits, total);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}

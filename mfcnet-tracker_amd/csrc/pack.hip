@@ -1,0 +1,65 @@
+// Weight packer / gradient unpacker (multi-job: one launch covers every convolution of the net).
+// Reference layout on both ends is nn.Conv2d.weight [Cout][Cin][KH][KW] fp32 (state_dict of
+// models/hrnet.py / models/multiframe_model.py).
+#include "common.h"
+
+template <typename J>
+__device__ inline int find_job(const J* jobs, int njobs, int bid) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const mfc_pack_job* jobs, int njobs) {
+    constexpr int E = Gran<T>::E;
+    const mfc_pack_job j = jobs[find_job(jobs, njobs, blockIdx.x)];
+    const long total = (long)j.TA * j.TB * j.Kg * j.Np;
+    long idx = (long)(blockIdx.x - j.block0) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int n = (int)(idx % j.Np); long r = idx / j.Np;
+    const int g = (int)(r % j.Kg); const int tap = (int)(r / j.Kg);
+    const int a = tap / j.TB, b = tap - a * j.TB;
+    const int kh = j.kh0 + a * j.kh_step, kw = j.kw0 + b * j.kw_step;
+    const float* src = (const float*)j.src;
+    float f[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = g * E + e;
+        int co, ci;
+        if (j.mode == 0) { co = n; ci = k; } else { co = k; ci = n; }
+        f[e] = (co < j.Cout && ci < j.Cin) ? src[(((size_t)co * j.Cin + ci) * j.KH + kh) * j.KW + kw] : 0.f;
+    }
+    ((uint4*)j.dst)[idx] = Gran<T>::pack(f);
+}
+
+extern "C" int mfc_pack_weights(const mfc_pack_job* jobs_dev, int32_t njobs, int32_t total_blocks, int32_t dtype, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0) return MFC_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFC_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs);
+    else if (dtype == MFC_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs);
+    else return MFC_ERR_INVALID_ARG;
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const mfc_unpack_job* jobs, int njobs) {
+    const mfc_unpack_job j = jobs[find_job(jobs, njobs, blockIdx.x)];
+    const long total = (long)j.Cout * j.Cin * j.KH * j.KW;
+    long idx = (long)(blockIdx.x - j.block0) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int kk = j.KH * j.KW;
+    const int tap = (int)(idx % kk); long r = idx / kk;
+    const int ci = (int)(r % j.Cin); const int co = (int)(r / j.Cin);
+    ((float*)j.dst)[idx] = ((const float*)j.src)[((size_t)tap * j.Co16 + co) * j.Ci16 + ci];
+}
+
+extern "C" int mfc_unpack_wgrad(const mfc_unpack_job* jobs_dev, int32_t njobs, int32_t total_blocks, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0) return MFC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}

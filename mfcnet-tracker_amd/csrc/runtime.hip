@@ -1,0 +1,199 @@
+// Loss, Adam and the program interpreter of libmfcnet_hip (gfx950).
+//   mfc_loss_fwd/bwd   F.log_softmax + class-weighted NLL + soft-Jaccard (src/engine.py:65-66, src/loss.py:31-63)
+//   mfc_adam_step      torch.optim.Adam over flat fp32 arenas (scripts/train_multiframe_detection.py:128-151)
+//   mfc_program_run    one host call enqueues a whole forward or backward pass
+#include "common.h"
+#include <math.h>
+
+// acc layout: [0] sum w_t*(-logp_t)  [1] sum w_t  [2+c] I_c  [10+c] P_c = sum p_c  [18+c] T_c = sum [t==c]
+//             [26] nll  [27] soft-jaccard  [28] total
+__global__ __launch_bounds__(256) void loss_fwd_kernel(mfc_loss_desc d, long total) {
+    __shared__ float red[26];
+    if (threadIdx.x < 26) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    const long HW = (long)d.H * d.W;
+    float a0 = 0.f, a1 = 0.f, I[8], P[8], Tc[8];
+    for (int c = 0; c < 8; ++c) { I[c] = 0.f; P[c] = 0.f; Tc[c] = 0.f; }
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long b = idx / HW, r = idx - b * HW;
+        float x[8], mx = -3.4e38f;
+        for (int c = 0; c < d.nc; ++c) { x[c] = d.logits[(b * d.nc + c) * HW + r]; mx = fmaxf(mx, x[c]); }
+        float se = 0.f;
+        for (int c = 0; c < d.nc; ++c) se += expf(x[c] - mx);
+        const float lse = mx + logf(se);
+        const int t = (int)d.target[idx];
+        const float wt = d.class_w ? d.class_w[t] : 1.f;
+        a0 += wt * (lse - x[t]); a1 += wt;
+        for (int c = 1; c < d.nc; ++c) {
+            const float pc = expf(x[c] - lse);
+            P[c] += pc;
+            if (t == c) { I[c] += pc; Tc[c] += 1.f; }
+        }
+    }
+    // wave reduce then LDS atomics
+    for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off);
+        for (int c = 1; c < d.nc; ++c) { I[c] += __shfl_down(I[c], off); P[c] += __shfl_down(P[c], off); Tc[c] += __shfl_down(Tc[c], off); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&red[0], a0); atomicAdd(&red[1], a1);
+        for (int c = 1; c < d.nc; ++c) { atomicAdd(&red[2 + c], I[c]); atomicAdd(&red[10 + c], P[c]); atomicAdd(&red[18 + c], Tc[c]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 26 && red[threadIdx.x] != 0.f) atomicAdd(d.acc + threadIdx.x, red[threadIdx.x]);
+}
+
+__global__ void loss_finalize_kernel(mfc_loss_desc d) {
+    if (threadIdx.x != 0) return;
+    const float eps = 1e-15f;
+    const float nll = d.acc[0] / d.acc[1];
+    float jac = 0.f;
+    for (int c = 1; c < d.nc; ++c) {
+        const float I = d.acc[2 + c], U = d.acc[10 + c] + d.acc[18 + c] - I;
+        jac += -logf((I + eps) / (U + eps));
+    }
+    jac /= (float)d.nc;
+    d.acc[26] = nll; d.acc[27] = jac; d.acc[28] = d.w_nll * nll + d.w_jac * jac;
+}
+
+static int loss_check(const mfc_loss_desc* d) {
+    if (!d || !d->logits || !d->target || !d->acc || d->nc < 2 || d->nc > 8 || d->B <= 0) return MFC_ERR_INVALID_ARG;
+    return MFC_OK;
+}
+
+extern "C" int mfc_loss_fwd(const mfc_loss_desc* d, void* stream) {
+    int rc = loss_check(d); if (rc < 0) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(d->acc, 0, 32 * sizeof(float), st) != hipSuccess) return MFC_ERR_LAUNCH;
+    const long total = (long)d->B * d->H * d->W;
+    long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3((int)blocks), dim3(256), 0, st, *d, total);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, *d);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_kernel(mfc_loss_desc d, long total) {
+    const float eps = 1e-15f;
+    const long HW = (long)d.H * d.W;
+    const float Wsum = d.acc[1];
+    float aI[8], aU[8];
+    for (int c = 0; c < 8; ++c) { aI[c] = 0.f; aU[c] = 0.f; }
+    for (int c = 1; c < d.nc; ++c) {
+        const float I = d.acc[2 + c], U = d.acc[10 + c] + d.acc[18 + c] - I;
+        aI[c] = -1.f / ((I + eps) * (float)d.nc);     // d/dp_c where t == c  (dU/dp_c = 0 there)
+        aU[c] = 1.f / ((U + eps) * (float)d.nc);      // d/dp_c where t != c
+    }
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long b = idx / HW, r = idx - b * HW;
+        float x[8], mx = -3.4e38f;
+        for (int c = 0; c < d.nc; ++c) { x[c] = d.logits[(b * d.nc + c) * HW + r]; mx = fmaxf(mx, x[c]); }
+        float se = 0.f;
+        for (int c = 0; c < d.nc; ++c) se += expf(x[c] - mx);
+        const float lse = mx + logf(se);
+        const int t = (int)d.target[idx];
+        const float wt = (d.class_w ? d.class_w[t] : 1.f) / Wsum;
+        float p[8], a[8], dot = 0.f;
+        for (int c = 0; c < d.nc; ++c) {
+            p[c] = expf(x[c] - lse);
+            a[c] = c == 0 ? 0.f : (t == c ? aI[c] : aU[c]);
+            dot += a[c] * p[c];
+        }
+        for (int c = 0; c < d.nc; ++c) {
+            const float gn = wt * (p[c] - (c == t ? 1.f : 0.f));
+            const float gj = p[c] * (a[c] - dot);
+            d.dlogits[(b * d.nc + c) * HW + r] = d.grad_scale * (d.w_nll * gn + d.w_jac * gj);
+        }
+    }
+}
+
+extern "C" int mfc_loss_bwd(const mfc_loss_desc* d, void* stream) {
+    int rc = loss_check(d); if (rc < 0) return rc;
+    if (!d->dlogits) return MFC_ERR_INVALID_ARG;
+    const long total = (long)d->B * d->H * d->W;
+    long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, *d, total);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float step_size,
+                                                   float beta1, float beta2, float eps, float inv_bc2_sqrt, float gscale) {
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
+        float* pp = (float*)&P; float* gg = (float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * gscale;
+            mm[k] = mm[k] + (gk - mm[k]) * (1.f - beta1);
+            vv[k] = vv[k] * beta2 + gk * gk * (1.f - beta2);
+            pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) * inv_bc2_sqrt + eps);
+        }
+        *(float4*)(p + i) = P; *(float4*)(m + i) = M; *(float4*)(v + i) = V;
+    } else {
+        for (long k = i; k < n; ++k) {
+            const float gk = g[k] * gscale;
+            m[k] = m[k] + (gk - m[k]) * (1.f - beta1);
+            v[k] = v[k] * beta2 + gk * gk * (1.f - beta2);
+            p[k] -= step_size * m[k] / (sqrtf(v[k]) * inv_bc2_sqrt + eps);
+        }
+    }
+}
+
+extern "C" int mfc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, int32_t step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return MFC_ERR_INVALID_ARG;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MFC_ERR_INVALID_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    const long blocks = ((n + 3) / 4 + 255) / 256;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// ------------------------------------------------------------------ program interpreter
+extern "C" int mfc_op_size(void) { return (int)sizeof(mfc_op); }
+extern "C" const char* mfc_version(void) { return "mfcnet_hip 0.1 (gfx950)"; }
+
+extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
+    if (!ops || n < 0) return MFC_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i) {
+        const mfc_op& o = ops[i];
+        int rc = MFC_ERR_UNSUPPORTED;
+        switch (o.kind) {
+            case MFC_OP_CONV: rc = mfc_conv2d_fwd(&o.u.conv, stream); break;
+            case MFC_OP_WGRAD: rc = mfc_conv2d_wgrad(&o.u.wgrad, stream); break;
+            case MFC_OP_BNFIN: rc = mfc_bn_finalize(&o.u.bnfin, stream); break;
+            case MFC_OP_COMBINE: rc = mfc_combine_fwd(&o.u.combine, stream); break;
+            case MFC_OP_BNBWD_REDUCE: rc = mfc_bnbwd_reduce(&o.u.bnbwd, stream); break;
+            case MFC_OP_BNBWD_FIN: rc = mfc_bnbwd_finalize(&o.u.bnbwdfin, stream); break;
+            case MFC_OP_BNBWD_APPLY: rc = mfc_bnbwd_apply(&o.u.bnbwd, stream); break;
+            case MFC_OP_MASK_ADD: rc = mfc_mask_add(&o.u.maskadd, stream); break;
+            case MFC_OP_HEAD_FWD: rc = mfc_head_gather_fwd(&o.u.head, stream); break;
+            case MFC_OP_HEAD_BWD: rc = mfc_head_gather_bwd(&o.u.headbwd.d, (void*)o.u.headbwd.dlogits, stream); break;
+            case MFC_OP_BIAS_GRAD:   // a = dy, b = db, n = npix, i[0]=dtype, i[1]=Cp, i[2]=C
+                rc = mfc_bias_grad((const void*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.n, o.u.raw.i[1], o.u.raw.i[2], stream); break;
+            case MFC_OP_MEMSET:      // a = ptr, n = bytes
+                rc = hipMemsetAsync((void*)o.u.raw.a, 0, (size_t)o.u.raw.n, st) == hipSuccess ? MFC_OK : MFC_ERR_LAUNCH; break;
+            case MFC_OP_PACK:        // a = jobs, i[0]=njobs, i[1]=total_blocks, i[2]=dtype
+                rc = mfc_pack_weights((const mfc_pack_job*)o.u.raw.a, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], stream); break;
+            case MFC_OP_UNPACK:      // a = jobs, i[0]=njobs, i[1]=total_blocks
+                rc = mfc_unpack_wgrad((const mfc_unpack_job*)o.u.raw.a, o.u.raw.i[0], o.u.raw.i[1], stream); break;
+            case MFC_OP_NCHW2NHWC:   // a = src, b = dst, i = dtype,N,C,H,W,Cp,c_off
+                rc = mfc_nchw_to_nhwc((const float*)o.u.raw.a, (void*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3],
+                                      o.u.raw.i[4], o.u.raw.i[5], o.u.raw.i[6], 1, stream); break;
+            case MFC_OP_NHWC2NCHW:   // a = src, b = dst, i = dtype,N,C,H,W,Cp
+                rc = mfc_nhwc_to_nchw((const void*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3],
+                                      o.u.raw.i[4], o.u.raw.i[5], stream); break;
+            default: rc = MFC_ERR_INVALID_ARG;
+        }
+        if (rc != MFC_OK) return -(1000 * (i + 1)) + rc;
+    }
+    return MFC_OK;
+}

@@ -1,0 +1,9 @@
+"""mfcnet_amd -- MI355X-native MFCNet multi-frame forward/backward hot path.
+
+Drop-in for the reference's `models.get_multiframe_segmentation_model` on the
+`HRNetMulti-Large` / `HRNetMulti-Basic` model types (models/__init__.py:79-84).
+"""
+from ._lib import BF16, F32, MfcError, lib  # noqa: F401  (importing loads libmfcnet_hip.so or raises)
+from .model import HRNetMultiBasic, HRNetMultiLarge, get_multiframe_segmentation_model  # noqa: F401
+from .optim import FlatAdam  # noqa: F401
+from .loss import mfc_loss  # noqa: F401

@@ -1,0 +1,169 @@
+"""ctypes binding of libmfcnet_hip.so (C ABI declared in include/mfcnet_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing, importing
+this module raises, and every op fails loudly rather than silently running
+PyTorch operators instead.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfcnet_hip.so")
+
+F32, BF16 = 0, 1
+STAT_REPLICAS = 32
+
+# op kinds (mfc_op_kind)
+OP_CONV, OP_WGRAD, OP_BNFIN, OP_COMBINE, OP_BNBWD_REDUCE, OP_BNBWD_FIN, OP_BNBWD_APPLY, OP_MASK_ADD = range(1, 9)
+OP_HEAD_FWD, OP_HEAD_BWD, OP_BIAS_GRAD, OP_MEMSET, OP_PACK, OP_UNPACK, OP_NCHW2NHWC, OP_NHWC2NCHW = range(9, 17)
+
+i32, u64, f32, vp = C.c_int32, C.c_uint64, C.c_float, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("inp", vp), ("wp", vp), ("out", vp), ("bias", vp), ("in_coef", vp), ("out_stats", vp),
+                ("dtype", i32), ("N", i32), ("Hin", i32), ("Win", i32), ("Cin_p", i32), ("Cin", i32),
+                ("Hout", i32), ("Wout", i32), ("Cout_p", i32), ("Cout", i32), ("Hl", i32), ("Wl", i32),
+                ("TA", i32), ("TB", i32), ("dh0", i32), ("dw0", i32), ("in_stride", i32),
+                ("out_sh", i32), ("out_sw", i32), ("out_oh", i32), ("out_ow", i32),
+                ("in_relu", i32), ("images_per_group", i32), ("accumulate", i32), ("TH", i32), ("TW", i32)]
+
+
+class PackJob(C.Structure):
+    _fields_ = [("src", u64), ("dst", u64), ("Cout", i32), ("Cin", i32), ("KH", i32), ("KW", i32),
+                ("TA", i32), ("TB", i32), ("kh0", i32), ("kh_step", i32), ("kw0", i32), ("kw_step", i32),
+                ("mode", i32), ("Kg", i32), ("Np", i32), ("block0", i32), ("nblocks", i32), ("pad_", i32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", vp), ("dy", vp), ("dwp", vp), ("in_coef", vp),
+                ("dtype", i32), ("N", i32), ("Hin", i32), ("Win", i32), ("Cin_p", i32), ("Cin", i32),
+                ("Hout", i32), ("Wout", i32), ("Cout_p", i32), ("Cout", i32),
+                ("TA", i32), ("TB", i32), ("dh0", i32), ("dw0", i32), ("in_stride", i32),
+                ("in_relu", i32), ("images_per_group", i32), ("TH", i32), ("TW", i32), ("splits", i32)]
+
+
+class UnpackJob(C.Structure):
+    _fields_ = [("src", u64), ("dst", u64), ("Cout", i32), ("Cin", i32), ("KH", i32), ("KW", i32),
+                ("Co16", i32), ("Ci16", i32), ("block0", i32), ("nblocks", i32)]
+
+
+class BnFinDesc(C.Structure):
+    _fields_ = [("stats", vp), ("coef", vp), ("gamma", vp), ("beta", vp), ("running_mean", vp),
+                ("running_var", vp), ("num_batches_tracked", vp),
+                ("C", i32), ("Cp", i32), ("G", i32), ("training", i32), ("count", f32), ("eps", f32), ("momentum", f32)]
+
+
+class View(C.Structure):
+    _fields_ = [("ptr", u64), ("coef", u64), ("H", i32), ("W", i32), ("Cp", i32), ("c_off", i32)]
+
+
+class CombineDesc(C.Structure):
+    _fields_ = [("out", View), ("src", View * 4), ("nsrc", i32), ("relu", i32), ("dtype", i32),
+                ("N", i32), ("C", i32), ("images_per_group", i32)]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [("g", View), ("y", View), ("mask", View), ("dy", View), ("bstats", vp), ("bcoef", vp),
+                ("mask_mode", i32), ("dtype", i32), ("N", i32), ("C", i32), ("images_per_group", i32), ("accumulate", i32)]
+
+
+class BnBwdFinDesc(C.Structure):
+    _fields_ = [("bstats", vp), ("bcoef", vp), ("dgamma", vp), ("dbeta", vp),
+                ("C", i32), ("Cp", i32), ("G", i32), ("training", i32), ("count", f32)]
+
+
+class MaskAddDesc(C.Structure):
+    _fields_ = [("g", View), ("mask", View), ("dst", View),
+                ("mask_mode", i32), ("dtype", i32), ("N", i32), ("C", i32), ("accumulate", i32)]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [("logits", vp), ("flow", vp * 8), ("depth", vp * 8), ("xh", vp),
+                ("dtype", i32), ("B", i32), ("T", i32), ("nc", i32), ("Hs", i32), ("Ws", i32), ("Lp", i32),
+                ("H", i32), ("W", i32), ("Cp", i32), ("warp", i32)]
+
+
+class HeadBwd(C.Structure):
+    _fields_ = [("d", HeadDesc), ("dlogits", u64)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("logits", vp), ("target", vp), ("class_w", vp), ("acc", vp), ("dlogits", vp),
+                ("B", i32), ("nc", i32), ("H", i32), ("W", i32), ("w_nll", f32), ("w_jac", f32), ("grad_scale", f32)]
+
+
+class RawOp(C.Structure):
+    _fields_ = [("a", u64), ("b", u64), ("c", u64), ("n", C.c_int64), ("i", i32 * 12)]
+
+
+class OpUnion(C.Union):
+    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("bnfin", BnFinDesc), ("combine", CombineDesc),
+                ("bnbwd", BnBwdDesc), ("bnbwdfin", BnBwdFinDesc), ("maskadd", MaskAddDesc), ("head", HeadDesc),
+                ("headbwd", HeadBwd), ("raw", RawOp), ("bytes", C.c_uint8 * 248)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", i32), ("pad_", i32), ("u", OpUnion)]
+
+
+# every symbol include/mfcnet_hip.h declares
+EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_unpack_wgrad",
+           "mfc_bn_finalize", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
+           "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
+           "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_bwd", "mfc_adam_step", "mfc_program_run",
+           "mfc_set_flag", "mfc_op_size", "mfc_version"]
+
+
+class MfcError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise MfcError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
+                       f"`make -C mfcnet-tracker_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise MfcError(f"{LIB_PATH} does not export {name}")
+    lib.mfc_version.restype = C.c_char_p
+    for name in EXPORTS:
+        if name not in ("mfc_version",):
+            getattr(lib, name).restype = C.c_int
+    lib.mfc_program_run.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.mfc_bias_grad.argtypes = [vp, vp, i32, C.c_int64, i32, i32, vp]
+    lib.mfc_nchw_to_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.mfc_nhwc_to_nchw.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.mfc_pack_weights.argtypes = [vp, i32, i32, i32, vp]
+    lib.mfc_unpack_wgrad.argtypes = [vp, i32, i32, vp]
+    lib.mfc_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, f32, f32, f32, f32, i32, f32, vp]
+    lib.mfc_head_gather_bwd.argtypes = [vp, vp, vp]
+    for name in ("mfc_conv2d_fwd", "mfc_conv2d_wgrad", "mfc_bn_finalize", "mfc_combine_fwd", "mfc_bnbwd_reduce",
+                 "mfc_bnbwd_apply", "mfc_bnbwd_finalize", "mfc_mask_add", "mfc_head_gather_fwd", "mfc_loss_fwd",
+                 "mfc_loss_bwd"):
+        getattr(lib, name).argtypes = [vp, vp]
+    lib.mfc_conv2d_lds_bytes.argtypes = [vp]
+    lib.mfc_set_flag.argtypes = [i32, i32]
+    if lib.mfc_op_size() != C.sizeof(Op):
+        raise MfcError(f"mfc_op size mismatch: library {lib.mfc_op_size()} vs python mirror {C.sizeof(Op)}")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "mfc call"):
+    if rc != 0:
+        raise MfcError(f"{what} failed with status {rc}")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(fn, desc, what=None):
+    check(fn(C.byref(desc), stream_ptr()), what or fn.__name__)

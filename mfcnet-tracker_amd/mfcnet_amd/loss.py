@@ -1,0 +1,47 @@
+"""Fused log_softmax + class-weighted NLL + soft-Jaccard on device (src/engine.py:65-66, src/loss.py:6-63).
+
+`mfc_loss(logits, target, ...)` returns (total_loss_tensor, acc) where `acc[26:29]` holds
+(nll, soft_jaccard, total) as device scalars -- no `.item()` host sync is needed inside the step
+(the reference syncs three times per step).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+DEFAULT_CLASS_WEIGHTS = (1.0, 1000.0, 1000.0, 1000.0, 1000.0)
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, class_w, w_nll, w_jac):
+        logits = logits.contiguous().float()
+        target = target.contiguous()
+        B, nc, H, W = logits.shape
+        acc = torch.empty(32, dtype=torch.float32, device=logits.device)
+        d = L.LossDesc(logits.data_ptr(), target.data_ptr(), class_w.data_ptr(), acc.data_ptr(), 0, B, nc, H, W, w_nll, w_jac, 1.0)
+        L.call(L.lib.mfc_loss_fwd, d)
+        ctx.save_for_backward(logits, target, class_w, acc)
+        ctx.w = (w_nll, w_jac)
+        ctx.mark_non_differentiable(acc)
+        return acc[28].clone(), acc
+
+    @staticmethod
+    def backward(ctx, gtot, _gacc):
+        logits, target, class_w, acc = ctx.saved_tensors
+        B, nc, H, W = logits.shape
+        dl = torch.empty_like(logits)
+        d = L.LossDesc(logits.data_ptr(), target.data_ptr(), class_w.data_ptr(), acc.data_ptr(), dl.data_ptr(), B, nc, H, W,
+                       ctx.w[0], ctx.w[1], 1.0)
+        L.call(L.lib.mfc_loss_bwd, d)
+        return dl * gtot, None, None, None, None
+
+
+def mfc_loss(logits, target, class_weights=DEFAULT_CLASS_WEIGHTS, w_nll=0.7, w_jac=0.3):
+    if not logits.is_cuda:
+        raise L.MfcError("mfc_loss runs on the GPU only")
+    cw = torch.as_tensor(class_weights, dtype=torch.float32, device=logits.device)
+    if target.dtype != torch.int64:
+        target = target.long()
+    return _LossFn.apply(logits, target, cw, float(w_nll), float(w_jac))

@@ -1,0 +1,567 @@
+"""Execution plan of the MFCNet hot path: a static, flat program of HIP kernel launches.
+
+The reference evaluates `HRNetMulti{Large,Basic}.forward` (models/multiframe_model.py:424-471) as a
+Python loop over T frames of a nested nn.Module tree (models/hrnet.py:425-476) and lets autograd
+replay ~5000 operator nodes backwards.  Here the same arithmetic is *planned once* per
+(batch, resolution, inputs, mode): every activation, gradient, statistic and packed-weight image gets
+a fixed address in one of five HBM arenas (288 GB per GPU: nothing is recomputed or re-allocated), the T
+frames are batched as N = T*B images with T BatchNorm statistic groups, and the forward and backward
+passes become two arrays of `mfc_op` records that libmfcnet_hip executes from ONE host call each
+(mfc_program_run) -- no per-op Python, no autograd graph, capturable in a hipGraph.
+
+Fusions the plan encodes:
+  * conv -> BN -> ReLU -> conv chains never materialise the normalised activation: the producer's
+    conv epilogue accumulates per-(group,channel) sum / sum-of-squares, `BNFIN` turns them into
+    scale/shift, and the consumer conv (and its wgrad) applies scale/shift/ReLU while staging its input;
+  * residual adds, fuse-layer sums, bilinear up-sampling and the final ReLU are one `COMBINE` pass;
+  * the x4 logit up-sampling, the temporal concat and flow/depth inputs are one `HEAD_FWD` pass.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from .arch import branch_widths, head_in_channels
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1          # nn.BatchNorm defaults; hrnet.py:34
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Arena:
+    def __init__(self, name):
+        self.name, self.size, self.base, self.buf = name, 0, 0, None
+
+    def alloc(self, nbytes, align=256):
+        off = rup(self.size, align)
+        self.size = off + nbytes
+        return off
+
+    def reset(self):
+        self.size = 0
+
+
+@dataclass
+class Ten:
+    N: int
+    H: int
+    W: int
+    C: int
+    Cp: int
+    ipg: int
+    ptr: int
+    nbytes: int
+    name: str = ""
+    needs_grad: bool = True
+    grad: Optional["Ten"] = None
+    grad_init: bool = False
+
+
+@dataclass
+class BN:
+    name: str
+    C: int
+    Cp: int
+    G: int
+    training: bool
+    count: float
+    stats: int
+    coef: int
+    bstats: int
+    bcoef: int
+
+
+@dataclass
+class Act:
+    t: Ten
+    bn: Optional[BN] = None      # virtual: consumers apply bn (+relu) on the fly
+    relu: bool = False
+
+
+@dataclass
+class Term:
+    t: Ten
+    bn: Optional[BN] = None
+    c_off: int = 0               # channel offset inside t (slices)
+
+
+@dataclass
+class ConvInfo:
+    wname: str
+    cout: int
+    cin: int
+    k: int
+    stride: int
+    pad: int
+    bias: Optional[str]
+    wp_fwd: int = 0
+    wp_dgrad: List[int] = field(default_factory=list)
+    dwp: int = 0
+
+
+class Plan:
+    def __init__(self, model, B, H, W, has_flow, has_depth, base_training, head_training, need_backward, device):
+        self.m = model
+        self.B, self.H, self.W = B, H, W
+        self.T, self.nc, self.width = model.num_frames, model.num_classes, model.width
+        self.basic = model.basic
+        self.has_flow, self.has_depth = has_flow, has_depth
+        self.dtype = model.compute_dtype
+        self.esz = 2 if self.dtype == L.BF16 else 4
+        self.E = 16 // self.esz
+        self.base_training, self.head_training = base_training, head_training
+        self.need_backward = need_backward
+        self.device = device
+        self.fuse_bn = model.fuse_bn
+        self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc")}
+        self._build()                       # dry pass: sizes
+        for a in self.arenas.values():
+            a.buf = torch.empty(max(a.size, 256) + 256, dtype=torch.uint8, device=device)
+            a.base = rup(a.buf.data_ptr(), 256)
+        self.arenas["misc"].buf.zero_()
+        self.arenas["act"].buf.zero_()
+        self._build()                       # real pass: pointers
+        self._finalize()
+
+    # ------------------------------------------------------------------ allocation helpers
+    def _alloc(self, arena, nbytes):
+        a = self.arenas[arena]
+        return a.base + a.alloc(nbytes)
+
+    def tensor(self, N, H, W, C, ipg, name="", needs_grad=True) -> Ten:
+        Cp = rup(C, 8)
+        nb = N * H * W * Cp * self.esz
+        return Ten(N, H, W, C, Cp, ipg, self._alloc("act", nb), nb, name, needs_grad)
+
+    def grad_of(self, t: Ten) -> Ten:
+        if t.grad is None:
+            t.grad = Ten(t.N, t.H, t.W, t.C, t.Cp, t.ipg, self._alloc("act", t.nbytes), t.nbytes, "d" + t.name)
+        return t.grad
+
+    def pptr(self, name):         # fp32 parameter pointer
+        return self.m._P.data_ptr() + 4 * self.m._poff[name]
+
+    def gptr(self, name):         # fp32 parameter-gradient pointer (into the flat gradient arena)
+        return self.grad_base + 4 * self.m._poff[name]
+
+    def bptr(self, name):         # running stats
+        return self.m._RS.data_ptr() + 4 * self.m._boff[name]
+
+    def new_bn(self, name, like: Ten, training) -> BN:
+        G = like.N // like.ipg
+        C_, Cp = like.C, like.Cp
+        R = L.STAT_REPLICAS
+        return BN(name, C_, Cp, G, training, float(like.ipg * like.H * like.W),
+                  self._alloc("stats", R * G * 2 * Cp * 4), self._alloc("misc", G * 4 * Cp * 4),
+                  self._alloc("bstats", R * G * 2 * Cp * 4) if self.need_backward else 0,
+                  self._alloc("misc", G * 2 * Cp * 4) if self.need_backward else 0)
+
+    def view(self, t: Ten, bn: Optional[BN] = None, c_off=0) -> L.View:
+        return L.View(t.ptr, bn.coef if bn else 0, t.H, t.W, t.Cp, c_off)
+
+    # ------------------------------------------------------------------ conv bookkeeping
+    def conv_info(self, wname, cout, cin, k, stride, bias) -> ConvInfo:
+        E = self.E
+        ci = ConvInfo(wname, cout, cin, k, stride, k // 2, (wname[:-6] + "bias") if bias else None)
+        Kg, Np = -(-cin // E), rup(cout, 16)
+        ci.wp_fwd = self._alloc("act", k * k * Kg * Np * 16)
+        src = self.pptr(wname)
+        self.pack_jobs.append(dict(src=src, dst=ci.wp_fwd, Cout=cout, Cin=cin, KH=k, KW=k, TA=k, TB=k, kh0=0, kh_step=1,
+                                   kw0=0, kw_step=1, mode=0, Kg=Kg, Np=Np))
+        if self.need_backward:
+            Kg2, Np2 = -(-cout // E), rup(cin, 16)
+            if stride == 1:
+                p = self._alloc("act", k * k * Kg2 * Np2 * 16)
+                ci.wp_dgrad = [p]
+                self.pack_jobs.append(dict(src=src, dst=p, Cout=cout, Cin=cin, KH=k, KW=k, TA=k, TB=k, kh0=k - 1,
+                                           kh_step=-1, kw0=k - 1, kw_step=-1, mode=1, Kg=Kg2, Np=Np2))
+            else:
+                assert stride == 2
+                ci.wp_dgrad = []
+                for ph in range(2):
+                    for pw in range(2):
+                        ta, kh0, _ = self._s2_class(k, ci.pad, ph)
+                        tb, kw0, _ = self._s2_class(k, ci.pad, pw)
+                        p = self._alloc("act", ta * tb * Kg2 * Np2 * 16)
+                        ci.wp_dgrad.append(p)
+                        self.pack_jobs.append(dict(src=src, dst=p, Cout=cout, Cin=cin, KH=k, KW=k, TA=ta, TB=tb, kh0=kh0,
+                                                   kh_step=-2, kw0=kw0, kw_step=-2, mode=1, Kg=Kg2, Np=Np2))
+            Co16, Ci16 = rup(cout, 16), rup(cin, 16)
+            ci.dwp = self._alloc("dwp", k * k * Co16 * Ci16 * 4)
+            self.unpack_jobs.append(dict(src=ci.dwp, dst=self.gptr(wname), Cout=cout, Cin=cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16))
+        return ci
+
+    @staticmethod
+    def _s2_class(k, pad, ph):
+        """stride-2 data-gradient, output parity class ph: (#taps, first kh, dh0); taps kh = kh0 - 2a."""
+        par = (ph + pad) % 2
+        khmax = k - 1 if (k - 1) % 2 == par else k - 2
+        return khmax // 2 + 1, khmax, (ph + pad - khmax) // 2
+
+    # ------------------------------------------------------------------ forward graph primitives
+    def conv(self, x: Act, wname, cout, k, stride=1, bias=False, bn_name=None, training=True) -> Act:
+        xt = x.t
+        pad = k // 2
+        Ho, Wo = (xt.H + 2 * pad - k) // stride + 1, (xt.W + 2 * pad - k) // stride + 1
+        y = self.tensor(xt.N, Ho, Wo, cout, xt.ipg, wname)
+        ci = self.conv_info(wname, cout, xt.C, k, stride, bias)
+        bn = self.new_bn(bn_name, y, training) if bn_name else None
+        d = L.ConvDesc(xt.ptr, ci.wp_fwd, y.ptr, self.pptr(ci.bias) if bias else 0, x.bn.coef if x.bn else 0,
+                       bn.stats if (bn and bn.training) else 0, self.dtype, xt.N, xt.H, xt.W, xt.Cp, xt.C,
+                       Ho, Wo, y.Cp, cout, Ho, Wo, k, k, -pad, -pad, stride, 1, 1, 0, 0,
+                       1 if x.relu else 0, xt.ipg, 0, 0, 0)
+        self.fwd.append((L.OP_CONV, d))
+        self.ops.append(("conv", x, y, ci, bn))
+        if bn:
+            self.fwd.append((L.OP_BNFIN, L.BnFinDesc(bn.stats, bn.coef, self.pptr(bn_name + ".weight"), self.pptr(bn_name + ".bias"),
+                                                     self.bptr(bn_name + ".running_mean"), self.bptr(bn_name + ".running_var"),
+                                                     self.m._NBT.data_ptr() + 8 * self.m._noff[bn_name + ".num_batches_tracked"],
+                                                     bn.C, bn.Cp, bn.G, 1 if bn.training else 0, bn.count, BN_EPS, BN_MOMENTUM)))
+            self.ops.append(("bnfin", y, bn))
+        return Act(y, bn, False)
+
+    def cbr(self, x: Act, conv_name, bn_name, cout, k, stride, relu, training) -> Act:
+        a = self.conv(x, conv_name + ".weight", cout, k, stride, False, bn_name, training)
+        a.relu = relu
+        if not self.fuse_bn:
+            return self.combine([Term(a.t, a.bn)], relu)
+        return a
+
+    def combine(self, terms: List[Term], relu, out: Optional[Ten] = None, out_c_off=0, C=None, size=None) -> Act:
+        t0 = terms[0].t
+        H, W = size if size else (t0.H, t0.W)
+        C = C if C is not None else t0.C
+        if out is None:
+            out = self.tensor(t0.N, H, W, C, t0.ipg, "cmb")
+        Cs = rup(C, self.E)
+        d = L.CombineDesc()
+        d.out = L.View(out.ptr, 0, out.H, out.W, out.Cp, out_c_off)
+        for i, tm in enumerate(terms):
+            d.src[i] = self.view(tm.t, tm.bn, tm.c_off)
+        d.nsrc, d.relu, d.dtype, d.N, d.C, d.images_per_group = len(terms), 1 if relu else 0, self.dtype, out.N, Cs, out.ipg
+        self.fwd.append((L.OP_COMBINE, d))
+        self.ops.append(("combine", terms, out, out_c_off, Cs, relu))
+        return Act(out, None, False)
+
+    # ------------------------------------------------------------------ the network
+    def _build(self):
+        for a in self.arenas.values():
+            a.reset()
+        self.fwd, self.bwd, self.ops = [], [], []
+        self.pack_jobs, self.unpack_jobs = [], []
+        m, B, T, H, W, nc = self.m, self.B, self.T, self.H, self.W, self.nc
+        self.grad_base = m._G.data_ptr()
+        f32 = lambda n: self._alloc("misc", 4 * n)
+        self.in_frames = [f32(B * 3 * H * W) for _ in range(T)]
+        self.in_flow = [f32(B * 2 * H * W) for _ in range(T - 1)] if self.has_flow else []
+        self.in_depth = [f32(B * H * W) for _ in range(T)] if self.has_depth else []
+        self.out_buf = f32(B * nc * H * W)
+        self.gout_buf = f32(B * nc * H * W) if self.need_backward else 0
+
+        # ---- input bridge: T NCHW fp32 frames -> one NHWC [T*B, H, W, 8] tensor (multiframe_model.py:459)
+        x0 = self.tensor(T * B, H, W, 3, B, "frames", needs_grad=False)
+        for t in range(T):
+            r = L.RawOp(self.in_frames[t], x0.ptr + t * B * H * W * x0.Cp * self.esz, 0, 0)
+            r.i[0:7] = [self.dtype, B, 3, H, W, x0.Cp, 0]
+            self.fwd.append((L.OP_NCHW2NHWC, r))
+        logits = self._hrnet(Act(x0))
+        # ---- head input: x4 up-sample + temporal concat (+flow, +depth, +warp)
+        basic_warp = self.basic and self.has_flow
+        cin = head_in_channels(self.basic, nc, T, self.has_flow, self.has_depth)
+        xh = self.tensor(B, H, W, cin, B, "head_in")
+        hd = L.HeadDesc()
+        hd.logits, hd.xh = logits.ptr, xh.ptr
+        for i, p in enumerate(self.in_flow):
+            hd.flow[i] = p
+        for i, p in enumerate(self.in_depth):
+            hd.depth[i] = p
+        hd.dtype, hd.B, hd.T, hd.nc, hd.Hs, hd.Ws, hd.Lp = self.dtype, B, T, nc, logits.H, logits.W, logits.Cp
+        hd.H, hd.W, hd.Cp, hd.warp = H, W, xh.Cp, 1 if basic_warp else 0
+        self.fwd.append((L.OP_HEAD_FWD, hd))
+        self.ops.append(("head", logits, xh, hd))
+        # ---- temporal aggregation head (multiframe_model.py:191-202)
+        q = "multiframe_net.multiframe_net."
+        ht = self.head_training
+        a = self.cbr(Act(xh), q + "0", q + "1", T * nc, 11, 1, True, ht)
+        a = self.cbr(a, q + "3", q + "4", T * nc, 3, 1, True, ht)
+        a = self.cbr(a, q + "6", q + "7", T * nc, 3, 1, True, ht)
+        o = self.conv(a, q + "9.weight", nc, 1).t
+        r = L.RawOp(o.ptr, self.out_buf, 0, 0)
+        r.i[0:6] = [self.dtype, B, nc, H, W, o.Cp]
+        self.fwd.append((L.OP_NHWC2NCHW, r))
+        self.ops.append(("out", o))
+        if self.need_backward:
+            self._emit_backward()
+
+    def _hrnet(self, x: Act) -> Ten:
+        """models/hrnet.py:425-476 as plan primitives; returns the low-resolution logits [T*B, H/4, W/4, nc]."""
+        p, tr = "base_model.", self.base_training
+        Wd = branch_widths(self.width)
+        x = self.cbr(x, p + "conv1", p + "bn1", 64, 3, 2, True, tr)
+        x = self.cbr(x, p + "conv2", p + "bn2", 64, 3, 2, True, tr)
+        for b in range(4):                                   # Bottleneck, hrnet.py:95-115
+            q = f"{p}layer1.{b}."
+            o = self.cbr(x, q + "conv1", q + "bn1", 64, 1, 1, True, tr)
+            o = self.cbr(o, q + "conv2", q + "bn2", 64, 3, 1, True, tr)
+            o = self.conv(o, q + "conv3.weight", 256, 1, 1, False, q + "bn3", tr)
+            if b == 0:
+                r = self.conv(x, q + "downsample.0.weight", 256, 1, 1, False, q + "downsample.1", tr)
+                res = Term(r.t, r.bn)
+            else:
+                res = Term(x.t)
+            x = self.combine([Term(o.t, o.bn), res], True)
+
+        def mat(a: Act) -> Act:                              # materialise relu(bn(y)) (needed as a residual)
+            return self.combine([Term(a.t, a.bn)], a.relu) if a.bn is not None else a
+
+        def transition(name, ys, pre, cur):                  # hrnet.py:353-389, 434-461
+            out = []
+            for i, c in enumerate(cur):
+                if i < len(pre):
+                    out.append(mat(self.cbr(ys[i], f"{p}{name}.{i}.0", f"{p}{name}.{i}.1", c, 3, 1, True, tr))
+                               if c != pre[i] else ys[i])
+                else:
+                    v = ys[-1]
+                    for j in range(i + 1 - len(pre)):
+                        co = c if j == i - len(pre) else pre[-1]
+                        v = self.cbr(v, f"{p}{name}.{i}.{j}.0", f"{p}{name}.{i}.{j}.1", co, 3, 2, True, tr)
+                    out.append(mat(v))
+            return out
+
+        def module(q, xs, ch, final_cat=None):               # HighResolutionModule.forward, hrnet.py:238-262
+            nb = len(xs)
+            xs = list(xs)
+            for i in range(nb):
+                v = xs[i]
+                for b in range(4):                           # BasicBlock, hrnet.py:58-74
+                    r = f"{q}branches.{i}.{b}."
+                    o = self.cbr(v, r + "conv1", r + "bn1", ch[i], 3, 1, True, tr)
+                    o = self.conv(o, r + "conv2.weight", ch[i], 3, 1, False, r + "bn2", tr)
+                    v = self.combine([Term(o.t, o.bn), Term(v.t)], True)
+                xs[i] = v
+            outs = []
+            for i in range(nb):
+                terms = []
+                for j in range(nb):
+                    r = f"{q}fuse_layers.{i}.{j}."
+                    if j == i:
+                        terms.append(Term(xs[j].t))
+                    elif j > i:                              # 1x1 + BN, then bilinear up-sampling
+                        o = self.conv(xs[j], r + "0.weight", ch[i], 1, 1, False, r + "1", tr)
+                        terms.append(Term(o.t, o.bn))
+                    else:                                    # chain of strided 3x3
+                        v = xs[j]
+                        for k in range(i - j):
+                            last = k == i - j - 1
+                            co = ch[i] if last else ch[j]
+                            if last:
+                                v = self.conv(v, f"{r}{k}.0.weight", co, 3, 2, False, f"{r}{k}.1", tr)
+                            else:
+                                v = self.cbr(v, f"{r}{k}.0", f"{r}{k}.1", co, 3, 2, True, tr)
+                        terms.append(Term(v.t, v.bn))
+                # reference sums in j order starting from j = 0
+                outs.append(self.combine(terms, True, size=(xs[i].t.H, xs[i].t.W), C=ch[i]))
+            return outs
+
+        ys = transition("transition1", [x], [256], Wd[:2])
+        ys = module(f"{p}stage2.0.", ys, Wd[:2])
+        ys = transition("transition2", ys, Wd[:2], Wd[:3])
+        for mi in range(4):
+            ys = module(f"{p}stage3.{mi}.", ys, Wd[:3])
+        ys = transition("transition3", ys, Wd[:3], Wd[:4])
+        for mi in range(3):
+            ys = module(f"{p}stage4.{mi}.", ys, Wd[:4])
+        # 4-way up-sample + concat (hrnet.py:464-469): four slice-writing combines
+        t0 = ys[0].t
+        cat = self.tensor(t0.N, t0.H, t0.W, sum(Wd), t0.ipg, "cat")
+        off = 0
+        for j in range(4):
+            self.combine([Term(ys[j].t)], False, out=cat, out_c_off=off, C=Wd[j], size=(t0.H, t0.W))
+            off += Wd[j]
+        o = self.conv(Act(cat), p + "last_layer.0.weight", sum(Wd), 1, 1, True, p + "last_layer.1", tr)
+        o.relu = True
+        if not self.fuse_bn:
+            o = self.combine([Term(o.t, o.bn)], True)
+        return self.conv(o, p + "last_layer.3.weight", self.nc, 1, 1, True).t
+
+    # ------------------------------------------------------------------ backward program
+    def _bn_backward(self, bn: BN, y: Ten, g_view: L.View, mask_mode, mask_view, dy_view: L.View, C):
+        d = L.BnBwdDesc()
+        d.g, d.y, d.dy = g_view, self.view(y, bn), dy_view
+        if mask_view is not None:
+            d.mask = mask_view
+        d.bstats, d.bcoef = bn.bstats, bn.bcoef
+        d.mask_mode, d.dtype, d.N, d.C, d.images_per_group, d.accumulate = mask_mode, self.dtype, y.N, C, y.ipg, 0
+        self.bwd.append((L.OP_BNBWD_REDUCE, d))
+        self.bwd.append((L.OP_BNBWD_FIN, L.BnBwdFinDesc(bn.bstats, bn.bcoef, self.gptr(bn.name + ".weight"),
+                                                        self.gptr(bn.name + ".bias"), bn.C, bn.Cp, bn.G,
+                                                        1 if bn.training else 0, bn.count)))
+        self.bwd.append((L.OP_BNBWD_APPLY, d))
+
+    def _emit_backward(self):
+        E, Cs = self.E, None
+        for op in reversed(self.ops):
+            kind = op[0]
+            if kind == "out":
+                o = op[1]
+                g = self.grad_of(o)
+                r = L.RawOp(self.gout_buf, g.ptr, 0, 0)
+                r.i[0:7] = [self.dtype, self.B, self.nc, self.H, self.W, g.Cp, 0]
+                self.bwd.append((L.OP_NCHW2NHWC, r))
+                o.grad_init = True
+            elif kind == "head":
+                _, logits, xh, hd = op
+                hb = L.HeadBwd()
+                C.memmove(C.byref(hb.d), C.byref(hd), C.sizeof(L.HeadDesc))
+                hb.d.xh = self.grad_of(xh).ptr
+                hb.dlogits = self.grad_of(logits).ptr
+                self.bwd.append((L.OP_HEAD_BWD, hb))
+                logits.grad_init = True
+            elif kind == "bnfin":
+                _, y, bn = op
+                if getattr(y, "virtual_consumed", False):
+                    g = self.grad_of(y)
+                    assert y.grad_init, y.name
+                    gv = L.View(g.ptr, 0, g.H, g.W, g.Cp, 0)
+                    self._bn_backward(bn, y, gv, 2 if getattr(y, "virtual_relu", False) else 0, None, gv, rup(y.C, E))
+            elif kind == "combine":
+                _, terms, out, out_c_off, Cs, relu = op
+                g = self.grad_of(out)
+                assert out.grad_init, out.name
+                gv = L.View(g.ptr, 0, g.H, g.W, g.Cp, out_c_off)
+                mv = L.View(out.ptr, 0, out.H, out.W, out.Cp, out_c_off) if relu else None
+                for tm in terms:
+                    s = tm.t
+                    if not s.needs_grad:
+                        continue
+                    sg = self.grad_of(s)
+                    same = (s.H == out.H and s.W == out.W)
+                    if tm.bn is None or not same:
+                        md = L.MaskAddDesc()
+                        md.g, md.dst = gv, L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
+                        if mv is not None:
+                            md.mask = mv
+                        acc = 1 if (s.grad_init and tm.bn is None) else 0
+                        md.mask_mode, md.dtype, md.N, md.C, md.accumulate = (1 if relu else 0), self.dtype, out.N, Cs, acc
+                        self.bwd.append((L.OP_MASK_ADD, md))
+                        s.grad_init = True
+                        if tm.bn is not None:       # up-sampled BN term: BN backward at the low resolution, in place
+                            sv = L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
+                            self._bn_backward(tm.bn, s, sv, 0, None, sv, Cs)
+                    else:
+                        assert not s.grad_init, s.name
+                        self._bn_backward(tm.bn, s, gv, 1 if relu else 0, mv, L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off), Cs)
+                        s.grad_init = True
+            elif kind == "conv":
+                _, x, y, ci, bn = op
+                dy = self.grad_of(y)
+                assert y.grad_init, y.name
+                xt = x.t
+                k, s, pad = ci.k, ci.stride, ci.pad
+                self.bwd.append((L.OP_WGRAD, L.WgradDesc(xt.ptr, dy.ptr, ci.dwp, x.bn.coef if x.bn else 0, self.dtype, xt.N, xt.H,
+                                                         xt.W, xt.Cp, xt.C, y.H, y.W, y.Cp, ci.cout, k, k, -pad, -pad, s,
+                                                         1 if x.relu else 0, xt.ipg, 0, 0, 0)))
+                if ci.bias:
+                    r = L.RawOp(dy.ptr, self.gptr(ci.bias), 0, y.N * y.H * y.W)
+                    r.i[0:3] = [self.dtype, y.Cp, ci.cout]
+                    self.bwd.append((L.OP_BIAS_GRAD, r))
+                if xt.needs_grad:
+                    dx = self.grad_of(xt)
+                    acc = 1 if xt.grad_init else 0
+                    if s == 1:
+                        self.bwd.append((L.OP_CONV, L.ConvDesc(dy.ptr, ci.wp_dgrad[0], dx.ptr, 0, 0, 0, self.dtype, y.N, y.H, y.W,
+                                                               y.Cp, ci.cout, xt.H, xt.W, xt.Cp, xt.C, xt.H, xt.W, k, k,
+                                                               -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, y.ipg, acc, 0, 0)))
+                    else:
+                        idx = 0
+                        for ph in range(2):
+                            for pw in range(2):
+                                ta, _, dh0 = self._s2_class(k, pad, ph)
+                                tb, _, dw0 = self._s2_class(k, pad, pw)
+                                Hl, Wl = (xt.H - ph + 1) // 2, (xt.W - pw + 1) // 2
+                                if Hl > 0 and Wl > 0:
+                                    self.bwd.append((L.OP_CONV, L.ConvDesc(dy.ptr, ci.wp_dgrad[idx], dx.ptr, 0, 0, 0, self.dtype, y.N, y.H,
+                                                                           y.W, y.Cp, ci.cout, xt.H, xt.W, xt.Cp, xt.C, Hl, Wl, ta, tb,
+                                                                           dh0, dw0, 1, 2, 2, ph, pw, 0, y.ipg, acc, 0, 0)))
+                                idx += 1
+                    xt.grad_init = True
+                    if x.bn is not None:
+                        xt.virtual_consumed, xt.virtual_relu = True, x.relu
+
+    # ------------------------------------------------------------------ program arrays
+    def _jobs(self, jobs, cls, per_block):
+        arr = (cls * len(jobs))()
+        b0 = 0
+        for i, j in enumerate(jobs):
+            for k_, v in j.items():
+                setattr(arr[i], k_, v)
+            if cls is L.PackJob:
+                total = j["TA"] * j["TB"] * j["Kg"] * j["Np"]
+            else:
+                total = j["Cout"] * j["Cin"] * j["KH"] * j["KW"]
+            nb = -(-total // per_block)
+            arr[i].block0, arr[i].nblocks = b0, nb
+            b0 += nb
+        dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        return dev, len(jobs), b0
+
+    def _program(self, recs):
+        arr = (L.Op * len(recs))()
+        for i, (kind, d) in enumerate(recs):
+            arr[i].kind = kind
+            C.memmove(C.byref(arr[i].u), C.byref(d), C.sizeof(d))
+        return arr
+
+    def _finalize(self):
+        st, bs, dw = self.arenas["stats"], self.arenas["bstats"], self.arenas["dwp"]
+        self._pack_dev, npk, nbk = self._jobs(self.pack_jobs, L.PackJob, 256)
+        pro = []
+        r = L.RawOp(st.base, 0, 0, st.size)
+        pro.append((L.OP_MEMSET, r))
+        r = L.RawOp(self._pack_dev.data_ptr(), 0, 0, 0)
+        r.i[0:3] = [npk, nbk, self.dtype]
+        pro.append((L.OP_PACK, r))
+        self.n_fwd_ops = len(self.fwd) + len(pro)
+        self.fwd_prog = self._program(pro + self.fwd)
+        if self.need_backward:
+            self._unpack_dev, nup, nbu = self._jobs(self.unpack_jobs, L.UnpackJob, 256)
+            pro = [(L.OP_MEMSET, L.RawOp(bs.base, 0, 0, bs.size)), (L.OP_MEMSET, L.RawOp(dw.base, 0, 0, dw.size)),
+                   (L.OP_MEMSET, L.RawOp(self.grad_base, 0, 0, self.m._G.numel() * 4))]
+            r = L.RawOp(self._unpack_dev.data_ptr(), 0, 0, 0)
+            r.i[0:2] = [nup, nbu]
+            self.bwd_prog = self._program(pro + self.bwd + [(L.OP_UNPACK, r)])
+        self.bytes_total = sum(a.size for a in self.arenas.values())
+
+    # ------------------------------------------------------------------ execution
+    def _io(self, off, shape):
+        a = self.arenas["misc"]
+        n = 1
+        for s in shape:
+            n *= s
+        o = off - a.buf.data_ptr()
+        return a.buf[o:o + 4 * n].view(torch.float32).view(shape)
+
+    def run_forward(self, frames, flow, depth):
+        B, T, H, W = self.B, self.T, self.H, self.W
+        for t in range(T):
+            self._io(self.in_frames[t], (B, 3, H, W)).copy_(frames[t])
+        for i, p in enumerate(self.in_flow):
+            self._io(p, (B, 2, H, W)).copy_(flow[i])
+        for i, p in enumerate(self.in_depth):
+            self._io(p, (B, 1, H, W)).copy_(depth[i])
+        rc = L.lib.mfc_program_run(self.fwd_prog, len(self.fwd_prog), L.stream_ptr())
+        if rc != 0:
+            raise L.MfcError(f"forward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
+        return self._io(self.out_buf, (B, self.nc, H, W)).clone()
+
+    def run_backward(self, grad_out):
+        self._io(self.gout_buf, (self.B, self.nc, self.H, self.W)).copy_(grad_out)
+        rc = L.lib.mfc_program_run(self.bwd_prog, len(self.bwd_prog), L.stream_ptr())
+        if rc != 0:
+            raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")

@@ -1,0 +1,364 @@
+"""Per-kernel parity tests: every C-ABI entry point against PyTorch CPU fp32 operators
+(F.conv2d / autograd / F.batch_norm / F.interpolate / torch.optim.Adam) on the same seeded inputs.
+
+Tolerances: fp32 kernels 2e-4 max-abs relative to the output scale (they use exact-fp32 MFMA, the
+difference is summation order); bf16 kernels are checked against the fp32 operator applied to the SAME
+bf16-rounded inputs, 1.5e-2 relative to the output scale (bf16 output rounding, fp32 accumulation).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import mfcnet_amd
+    from mfcnet_amd import _lib, ops
+    return mfcnet_amd, _lib, ops
+
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 1.5e-2}
+
+
+def rnd(dtype, *shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g) * scale
+    return x.to(dtype).float() if dtype == torch.bfloat16 else x
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+CONV_CASES = [  # N, Cin, Cout, k, s, H, W
+    (2, 48, 48, 3, 1, 24, 40), (2, 3, 64, 3, 2, 64, 96), (2, 64, 64, 3, 2, 32, 48), (3, 96, 192, 3, 2, 15, 20),
+    (2, 384, 384, 3, 1, 15, 20), (2, 256, 64, 1, 1, 16, 24), (1, 720, 720, 1, 1, 12, 20), (2, 720, 5, 1, 1, 16, 24),
+    (2, 15, 15, 11, 1, 32, 48), (1, 22, 15, 11, 1, 24, 40), (2, 15, 5, 1, 1, 16, 16), (1, 48, 96, 3, 2, 23, 30),
+    (2, 32, 32, 3, 1, 30, 40), (1, 128, 256, 3, 2, 30, 40), (2, 192, 48, 1, 1, 8, 10),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(M, case, dtype):
+    _, L, ops = M
+    N, Cin, Cout, k, s, H, W = case
+    x = rnd(dtype, N, Cin, H, W, seed=1)
+    w = rnd(dtype, Cout, Cin, k, k, seed=2, scale=1.0 / np.sqrt(Cin * k * k))
+    b = rnd(torch.float32, Cout, seed=3)
+    ref = F.conv2d(x, w, b, stride=s, padding=k // 2)
+    y = ops.conv2d(ops.to_nhwc(x, dtype), w.cuda(), k, s, bias=b.cuda())
+    out = ops.to_nchw(y, Cout).cpu()
+    assert relerr(out, ref) < TOL[dtype]
+    assert float(y[..., Cout:].float().abs().max() if y.shape[3] > Cout else 0.0) == 0.0   # channel padding stays zero
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_fused_bn_relu_input_and_stats(M, dtype):
+    """consumer-side BN-apply+ReLU (zero padding AFTER the transform) and the epilogue statistics."""
+    _, L, ops = M
+    N, Cin, Cout, H, W, G = 4, 48, 96, 20, 28, 2
+    x = rnd(dtype, N, Cin, H, W, seed=4)
+    w = rnd(dtype, Cout, Cin, 3, 3, seed=5, scale=0.05)
+    scale = torch.rand(G, Cin) + 0.5
+    shift = torch.randn(G, Cin) * 0.3
+    coef = torch.zeros(G, 4, Cin)
+    coef[:, 0], coef[:, 1] = scale, shift
+    xa = torch.cat([F.relu(x[g * 2:(g + 1) * 2] * scale[g].view(1, -1, 1, 1) + shift[g].view(1, -1, 1, 1)) for g in range(G)])
+    if dtype == torch.bfloat16:
+        xa = xa.bfloat16().float()
+    ref = F.conv2d(xa, w, None, padding=1)
+    stats = torch.zeros(L.STAT_REPLICAS, G, 2, Cout, device="cuda")
+    y = ops.conv2d(ops.to_nhwc(x, dtype), w.cuda(), 3, 1, in_coef=coef.cuda(), in_relu=True, ipg=2, stats=stats)
+    out = ops.to_nchw(y, Cout).cpu()
+    assert relerr(out, ref) < TOL[dtype]
+    st = stats.sum(0).cpu()
+    for g in range(G):
+        r = ref[g * 2:(g + 1) * 2]
+        assert relerr(st[g, 0], r.sum((0, 2, 3))) < 5 * TOL[dtype]
+        assert relerr(st[g, 1], (r * r).sum((0, 2, 3))) < 5 * TOL[dtype]
+
+
+DG_CASES = [(2, 48, 48, 3, 1, 24, 40), (2, 64, 64, 3, 2, 32, 48), (1, 48, 96, 3, 2, 23, 30), (2, 96, 48, 1, 1, 15, 20),
+            (1, 22, 15, 11, 1, 24, 40), (2, 192, 384, 3, 2, 30, 40), (2, 256, 96, 3, 2, 16, 24)]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", DG_CASES)
+def test_conv_dgrad(M, case, dtype):
+    _, L, ops = M
+    N, Cin, Cout, k, s, H, W = case
+    x = rnd(dtype, N, Cin, H, W, seed=6).requires_grad_(True)
+    w = rnd(dtype, Cout, Cin, k, k, seed=7, scale=1.0 / np.sqrt(Cin * k * k))
+    y = F.conv2d(x, w, None, stride=s, padding=k // 2)
+    dy = rnd(dtype, *y.shape, seed=8)
+    y.backward(dy)
+    dx = ops.conv2d_dgrad(ops.to_nhwc(dy, dtype), w.cuda(), k, s, (H, W))
+    assert relerr(ops.to_nchw(dx, Cin).cpu(), x.grad) < TOL[dtype]
+    # accumulate flag
+    dx2 = ops.conv2d_dgrad(ops.to_nhwc(dy, dtype), w.cuda(), k, s, (H, W), accumulate_into=dx.clone())
+    assert relerr(ops.to_nchw(dx2, Cin).cpu(), 2 * x.grad) < 2 * TOL[dtype]
+
+
+WG_CASES = [(2, 48, 48, 3, 1, 24, 40), (2, 3, 64, 3, 2, 64, 96), (2, 96, 96, 3, 1, 30, 40), (3, 96, 192, 3, 2, 15, 20),
+            (2, 384, 384, 3, 1, 15, 20), (2, 256, 64, 1, 1, 16, 24), (1, 720, 720, 1, 1, 12, 20), (2, 720, 5, 1, 1, 16, 24),
+            (2, 15, 15, 11, 1, 32, 48), (1, 22, 15, 11, 1, 24, 40), (1, 48, 96, 3, 2, 23, 30), (2, 32, 64, 3, 1, 17, 21)]
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_wgrad(M, case, dtype, tr):
+    _, L, ops = M
+    if dtype == torch.float32 and tr == 0:
+        pytest.skip("tr flag only affects bf16")
+    N, Cin, Cout, k, s, H, W = case
+    x = rnd(dtype, N, Cin, H, W, seed=9)
+    w = rnd(dtype, Cout, Cin, k, k, seed=10, scale=0.05).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=s, padding=k // 2)
+    dy = rnd(dtype, *y.shape, seed=11)
+    y.backward(dy)
+    L.lib.mfc_set_flag(1, tr)
+    try:
+        dw = ops.conv2d_wgrad(ops.to_nhwc(x, dtype), ops.to_nhwc(dy, dtype), Cout, Cin, k, s)
+    finally:
+        L.lib.mfc_set_flag(1, 1)
+    assert relerr(dw.cpu(), w.grad) < TOL[dtype]
+
+
+def test_wgrad_fused_input_transform(M):
+    _, L, ops = M
+    N, Cin, Cout, H, W = 2, 48, 48, 16, 24
+    x = rnd(torch.float32, N, Cin, H, W, seed=12)
+    scale, shift = torch.rand(1, Cin) + 0.5, torch.randn(1, Cin) * 0.3
+    coef = torch.zeros(1, 4, Cin)
+    coef[:, 0], coef[:, 1] = scale, shift
+    xa = F.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    w = rnd(torch.float32, Cout, Cin, 3, 3, seed=13, scale=0.05).requires_grad_(True)
+    y = F.conv2d(xa, w, None, padding=1)
+    dy = rnd(torch.float32, *y.shape, seed=14)
+    y.backward(dy)
+    dw = ops.conv2d_wgrad(ops.to_nhwc(x), ops.to_nhwc(dy), Cout, Cin, 3, 1, in_coef=coef.cuda(), in_relu=True)
+    assert relerr(dw.cpu(), w.grad) < 2e-4
+
+
+def test_bn_finalize_matches_batch_norm(M):
+    _, L, ops = M
+    G, ipg, Cc, H, W = 3, 2, 48, 10, 12
+    y = torch.randn(G * ipg, Cc, H, W, generator=torch.Generator().manual_seed(15)) * 2 + 0.5
+    gamma, beta = torch.rand(Cc) + 0.5, torch.randn(Cc)
+    rm, rv = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    outs = [F.batch_norm(y[g * ipg:(g + 1) * ipg], rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5) for g in range(G)]
+    stats = torch.zeros(L.STAT_REPLICAS, G, 2, Cc)
+    for g in range(G):
+        yy = y[g * ipg:(g + 1) * ipg]
+        stats[g % L.STAT_REPLICAS, g, 0] = yy.sum((0, 2, 3))
+        stats[(g + 5) % L.STAT_REPLICAS, g, 1] = (yy * yy).sum((0, 2, 3))
+    stats, coef = stats.cuda(), torch.zeros(G, 4, Cc, device="cuda")
+    dg, db, drm, drv = gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda()
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    d = L.BnFinDesc(stats.data_ptr(), coef.data_ptr(), dg.data_ptr(), db.data_ptr(), drm.data_ptr(), drv.data_ptr(),
+                    nbt.data_ptr(), Cc, Cc, G, 1, float(ipg * H * W), 1e-5, 0.1)
+    L.call(L.lib.mfc_bn_finalize, d)
+    coef = coef.cpu()
+    for g in range(G):
+        yy = y[g * ipg:(g + 1) * ipg]
+        mine = yy * coef[g, 0].view(1, -1, 1, 1) + coef[g, 1].view(1, -1, 1, 1)
+        assert float((mine - outs[g]).abs().max()) < 2e-5
+    assert float((drm.cpu() - rm_ref).abs().max()) < 1e-6 and float((drv.cpu() - rv_ref).abs().max()) < 1e-5
+    assert int(nbt) == G
+    # eval mode: coefficients from running stats
+    d.training = 0
+    L.call(L.lib.mfc_bn_finalize, d)
+    ref = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, False, 0.1, 1e-5)
+    c = coef.cpu() if False else torch.empty(0)
+    coef2 = torch.zeros(G, 4, Cc, device="cuda")
+    d.coef = coef2.data_ptr()
+    L.call(L.lib.mfc_bn_finalize, d)
+    c = coef2.cpu()
+    assert float((y * c[0, 0].view(1, -1, 1, 1) + c[0, 1].view(1, -1, 1, 1) - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_combine_residual_bilinear(M, dtype):
+    """fuse-layer sum: identity + BN(up-sampled conv output) + BN(same-res conv output), ReLU (hrnet.py:245-260)."""
+    _, L, ops = M
+    N, Cc, H, W = 2, 48, 24, 40
+    a = rnd(dtype, N, Cc, H, W, seed=16)
+    b = rnd(dtype, N, Cc, H // 2, W // 2, seed=17)
+    c = rnd(dtype, N, Cc, H, W, seed=18)
+    e = rnd(dtype, N, Cc, 5, 7, seed=19)               # non-integer scale
+    cb = torch.zeros(1, 4, Cc); cb[0, 0] = torch.rand(Cc) + 0.5; cb[0, 1] = torch.randn(Cc) * 0.2
+    cc = torch.zeros(1, 4, Cc); cc[0, 0] = torch.rand(Cc) + 0.5; cc[0, 1] = torch.randn(Cc) * 0.2
+    aff = lambda t, cf: t * cf[0, 0].view(1, -1, 1, 1) + cf[0, 1].view(1, -1, 1, 1)
+    ref = F.relu(a + F.interpolate(aff(b, cb), size=(H, W), mode="bilinear", align_corners=False) + aff(c, cc)
+                 + F.interpolate(e, size=(H, W), mode="bilinear", align_corners=False))
+    ta, tb, tc, te = (ops.to_nhwc(t, dtype) for t in (a, b, c, e))
+    out = torch.zeros_like(ta)
+    cbd, ccd = cb.cuda(), cc.cuda()
+    d = L.CombineDesc()
+    d.out = ops.view(out)
+    d.src[0], d.src[1], d.src[2], d.src[3] = ops.view(ta), ops.view(tb, cbd), ops.view(tc, ccd), ops.view(te)
+    d.nsrc, d.relu, d.dtype, d.N, d.C, d.images_per_group = 4, 1, ops.dt_of(ta), N, Cc, N
+    L.call(L.lib.mfc_combine_fwd, d)
+    assert relerr(ops.to_nchw(out, Cc).cpu(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("dtype", DT)
+def test_bn_backward(M, dtype, mode):
+    """BN(+ReLU / +residual ReLU) backward: reduce -> finalize -> apply vs autograd (train-mode BN, 2 groups)."""
+    _, L, ops = M
+    G, ipg, Cc, H, W = 2, 2, 48, 12, 20
+    N = G * ipg
+    y = rnd(dtype, N, Cc, H, W, seed=20).requires_grad_(True)
+    res = rnd(dtype, N, Cc, H, W, seed=21)
+    gamma = (torch.rand(Cc) + 0.5).requires_grad_(True)
+    beta = (torch.randn(Cc) * 0.2).requires_grad_(True)
+    zs = [F.batch_norm(y[g * ipg:(g + 1) * ipg], None, None, gamma, beta, True, 0.1, 1e-5) for g in range(G)]
+    z = torch.cat(zs)
+    a = z if mode == 0 else (F.relu(z + res) if mode == 1 else F.relu(z))
+    ga = rnd(dtype, N, Cc, H, W, seed=22)
+    a.backward(ga)
+    coef = torch.zeros(G, 4, Cc)
+    for g in range(G):
+        yy = y.detach()[g * ipg:(g + 1) * ipg]
+        mean, var = yy.mean((0, 2, 3)), yy.var((0, 2, 3), unbiased=False)
+        rstd = 1 / torch.sqrt(var + 1e-5)
+        coef[g, 0], coef[g, 1], coef[g, 2], coef[g, 3] = gamma.detach() * rstd, beta.detach() - mean * gamma.detach() * rstd, mean, rstd
+    ty, tg = ops.to_nhwc(y.detach(), dtype), ops.to_nhwc(ga, dtype)
+    ta = ops.to_nhwc(a.detach(), dtype)
+    coefd = coef.cuda()
+    bst = torch.zeros(L.STAT_REPLICAS, G, 2, Cc, device="cuda")
+    bco = torch.zeros(G, 2, Cc, device="cuda")
+    dgam, dbet = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    dy = torch.zeros_like(ty)
+    d = L.BnBwdDesc()
+    d.g, d.y, d.dy = ops.view(tg), ops.view(ty, coefd), ops.view(dy)
+    if mode == 1:
+        d.mask = ops.view(ta)
+    d.bstats, d.bcoef = bst.data_ptr(), bco.data_ptr()
+    d.mask_mode, d.dtype, d.N, d.C, d.images_per_group, d.accumulate = mode, ops.dt_of(ty), N, Cc, ipg, 0
+    L.call(L.lib.mfc_bnbwd_reduce, d)
+    f = L.BnBwdFinDesc(bst.data_ptr(), bco.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), Cc, Cc, G, 1, float(ipg * H * W))
+    L.call(L.lib.mfc_bnbwd_finalize, f)
+    L.call(L.lib.mfc_bnbwd_apply, d)
+    tol = TOL[dtype] * 2
+    assert relerr(ops.to_nchw(dy, Cc).cpu(), y.grad) < tol
+    assert relerr(dgam.cpu(), gamma.grad) < tol and relerr(dbet.cpu(), beta.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("hw", [((12, 20), (24, 40)), ((5, 7), (24, 40)), ((3, 5), (24, 40)), ((23, 30), (92, 120)), ((24, 40), (24, 40))])
+def test_mask_add_adjoint_bilinear(M, dtype, hw):
+    _, L, ops = M
+    (hs, ws), (H, W) = hw
+    N, Cc = 2, 48
+    src = rnd(dtype, N, Cc, hs, ws, seed=23).requires_grad_(True)
+    other = rnd(dtype, N, Cc, H, W, seed=24)
+    up = F.interpolate(src, size=(H, W), mode="bilinear", align_corners=False) if (hs, ws) != (H, W) else src
+    out = F.relu(up + other)
+    g = rnd(dtype, N, Cc, H, W, seed=25)
+    out.backward(g)
+    tg, tout = ops.to_nhwc(g, dtype), ops.to_nhwc(out.detach(), dtype)
+    dst = torch.ones(N, hs, ws, Cc, dtype=dtype, device="cuda")
+    d = L.MaskAddDesc()
+    d.g, d.mask, d.dst = ops.view(tg), ops.view(tout), ops.view(dst)
+    d.mask_mode, d.dtype, d.N, d.C, d.accumulate = 1, ops.dt_of(tg), N, Cc, 1
+    L.call(L.lib.mfc_mask_add, d)
+    assert relerr(ops.to_nchw(dst, Cc).cpu() - 1.0, src.grad) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("flow,depth", [(False, False), (True, True), (False, True)])
+def test_head_gather_fwd_bwd(M, dtype, flow, depth):
+    """x4 up-sample + temporal concat (hrnet.py:473-474, multiframe_model.py:459-469) and its adjoint."""
+    _, L, ops = M
+    B, T, nc, Hs, Ws = 2, 3, 5, 12, 20
+    H, W = 4 * Hs, 4 * Ws
+    lg = rnd(dtype, T * B, nc, Hs, Ws, seed=26).requires_grad_(True)
+    fl = [rnd(torch.float32, B, 2, H, W, seed=30 + i) for i in range(T - 1)] if flow else []
+    dp = [rnd(torch.float32, B, 1, H, W, seed=40 + i) for i in range(T)] if depth else []
+    ups = [F.interpolate(lg[t * B:(t + 1) * B], size=(H, W), mode="bilinear", align_corners=False) for t in range(T)]
+    ref = torch.cat(ups + fl + dp, 1)
+    cin = ref.shape[1]
+    Cp = (cin + 7) // 8 * 8
+    tl = ops.to_nhwc(lg.detach(), dtype)
+    xh = torch.full((B, H, W, Cp), 7.0, dtype=dtype, device="cuda")
+    fld, dpd = [f.cuda() for f in fl], [p.cuda() for p in dp]
+    d = L.HeadDesc()
+    d.logits, d.xh = tl.data_ptr(), xh.data_ptr()
+    for i, f in enumerate(fld):
+        d.flow[i] = f.data_ptr()
+    for i, p in enumerate(dpd):
+        d.depth[i] = p.data_ptr()
+    d.dtype, d.B, d.T, d.nc, d.Hs, d.Ws, d.Lp, d.H, d.W, d.Cp, d.warp = ops.dt_of(tl), B, T, nc, Hs, Ws, 8, H, W, Cp, 0
+    L.call(L.lib.mfc_head_gather_fwd, d)
+    got = ops.to_nchw(xh, cin).cpu()
+    want = ref.detach().to(dtype).float() if dtype == torch.bfloat16 else ref.detach()
+    assert relerr(got, want) < TOL[dtype]
+    assert float(xh[..., cin:].float().abs().max() if Cp > cin else 0) == 0
+    g = rnd(dtype, B, cin, H, W, seed=27)
+    ref.backward(g)
+    tg = ops.to_nhwc(g, dtype)
+    dl = torch.zeros_like(tl)
+    d.xh = tg.data_ptr()
+    L.check(L.lib.mfc_head_gather_bwd(C.byref(d), dl.data_ptr(), L.stream_ptr()))
+    assert relerr(ops.to_nchw(dl, nc).cpu(), lg.grad) < TOL[dtype] * 2
+
+
+def test_loss_fwd_bwd(M):
+    mfc, L, ops = M
+    from oracle import mfcnet_oracle as O
+    B, nc, H, W = 2, 5, 40, 56
+    g = torch.Generator().manual_seed(28)
+    logits = (torch.randn(B, nc, H, W, generator=g) * 2).requires_grad_(True)
+    target = torch.randint(0, nc, (B, H, W), generator=g)
+    tot, parts = O.total_loss(logits, target, nc)
+    tot.backward()
+    lg = logits.detach().cuda().requires_grad_(True)
+    loss, acc = mfc.mfc_loss(lg, target.cuda())
+    loss.backward()
+    acc = acc.cpu()
+    assert abs(float(acc[26]) - float(parts["loss_nll"])) < 1e-5
+    assert abs(float(acc[27]) - float(parts["loss_soft_jaccard"])) < 1e-5
+    assert abs(float(loss) - float(tot)) < 1e-5
+    assert relerr(lg.grad.cpu(), logits.grad) < 1e-4
+
+
+def test_adam_matches_torch(M):
+    _, L, ops = M
+    n = 10007
+    g = torch.Generator().manual_seed(29)
+    p0 = torch.randn(n, generator=g)
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=1e-3)
+    P, Mm, V = torch.zeros(10008, device="cuda"), torch.zeros(10008, device="cuda"), torch.zeros(10008, device="cuda")
+    P[:n] = p0.cuda()
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g)
+        p.grad = grad.clone()
+        opt.step()
+        G = torch.zeros(10008, device="cuda"); G[:n] = grad.cuda()
+        L.check(L.lib.mfc_adam_step(P.data_ptr(), G.data_ptr(), Mm.data_ptr(), V.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, step, 1.0, L.stream_ptr()))
+    assert float((P[:n].cpu() - p.detach()).abs().max()) < 1e-6
+
+
+def test_invalid_descriptors_are_rejected(M):
+    _, L, ops = M
+    d = L.ConvDesc()
+    assert L.lib.mfc_conv2d_fwd(C.byref(d), None) == -1
+    assert L.lib.mfc_program_run(None, 1, None) == -1
+    x = torch.zeros(1, 8, 8, 12, device="cuda")      # channel pitch not a multiple of 8
+    w = torch.zeros(8, 12, 3, 3, device="cuda")
+    with pytest.raises(L.MfcError):
+        ops.conv2d(x, w, 3, 1)
