@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Benchmark of the MFCNet hot path on MI355X: frames/s of the full training step
+(zero_grad -> forward -> fused log_softmax/NLL/soft-Jaccard -> backward -> Adam; src/engine.py:54-71)
+on synthetic 480x640 T=3 clips, BASELINE.json's metric.
+
+    python bench.py                                   # 1 GPU, width 32 (the metric's "HRNet-w32"), bf16, B=8
+    python bench.py --width 48                        # the reference's hard-coded HRNet-W48
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W     # one rank per GPU, RCCL all-reduce of the flat gradient arena
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every launch of the
+dominant kernel (the MFMA implicit-GEMM convolution) inside the timed steps; `cpu_baseline` times the CPU
+oracle (the restatement of the reference step, oracle/mfcnet_oracle.py) on this host's cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+NT_SLOTS = [1, 2, 3, 4, 6]
+
+
+def synth(B, T, H, W, nc, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    frames = [torch.randn(B, 3, H, W, generator=g).to(device) for _ in range(T)]
+    mask = torch.randint(0, nc, (B, H, W), generator=g).to(device)
+    return frames, mask
+
+
+def cpu_baseline(width, T, H, W, steps=2):
+    """The CPU oracle's training step on the host cores (bounded sample)."""
+    from oracle import mfcnet_oracle as O
+    torch.manual_seed(0)
+    sd = O.hashed_state(O.mfcnet_table("HRNetMulti-Large", width, 5, T, False, False))
+    net = O.Net(sd, "HRNetMulti-Large", width, 5, T).train()
+    opt = O.make_adam(net, 1e-4)
+    g = torch.Generator().manual_seed(42)
+    frames = [torch.randn(1, 3, H, W, generator=g) for _ in range(T)]
+    mask = torch.randint(0, 5, (1, H, W), generator=g)
+    O.train_step(net, opt, frames, mask)            # warm-up (allocator, thread pool)
+    t0 = time.time()
+    for _ in range(steps):
+        O.train_step(net, opt, frames, mask)
+    dt = time.time() - t0
+    return {"value": round(steps * T / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full training steps of the CPU oracle, HRNet-w{width} MFCNet, B=1, T={T}, {H}x{W}, fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=32, help="HRNet width: 32 = BASELINE.json metric label, 48 = reference")
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=3)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width-px", type=int, default=640)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import mfcnet_amd as mfc
+    from mfcnet_amd import _lib as L
+    from mfcnet_amd.dist import allreduce_grads
+
+    T, H, W, B, nc = args.frames, args.height, args.width_px, args.batch, 5
+    torch.manual_seed(1234)                                    # identical initial weights on every rank
+    model = mfc.HRNetMultiLarge(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype=args.dtype)
+    model = model.to(device).train()
+    opt = mfc.FlatAdam(model, lr=1e-4)
+    frames, mask = synth(B, T, H, W, nc, 42 + 2000 + rank, device)
+
+    def step():
+        opt.zero_grad()
+        out = model(frames)
+        loss, _ = mfc.mfc_loss(out, mask)
+        loss.backward()
+        if world > 1:
+            allreduce_grads(model, world)
+        opt.step()
+        return loss
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if not args.no_prof:
+        L.lib.mfc_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    L.lib.mfc_prof_enable(0)
+    prof = L.ProfResult()
+    L.lib.mfc_prof_collect(C.byref(prof))
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    final_loss = float(loss)
+
+    if rank == 0:
+        # dominant kernel = the conv_igemm instantiation with the largest total time
+        base = 8 if args.dtype == "bf16" else 0
+        best, roof = None, None
+        tot_conv_ms = sum(prof.ms[i] for i in range(32))
+        for slot, nt in enumerate(NT_SLOTS):
+            b = base + slot
+            if prof.launches[b] and (best is None or prof.ms[b] > prof.ms[best]):
+                best = b
+        if best is not None:
+            n = prof.launches[best]
+            avg_ms = prof.ms[best] / n
+            achieved = prof.flops[best] / n / (avg_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.dtype]
+            fam_ms = sum(prof.ms[base + s] for s in range(5))
+            fam_fl = sum(prof.flops[base + s] for s in range(5))
+            wg_ms = sum(prof.ms[16 + base + s] for s in range(3))
+            wg_fl = sum(prof.flops[16 + base + s] for s in range(3))
+            roof = {"bound": "mfma", "kernel": f"conv_igemm_kernel<{'bf16' if args.dtype == 'bf16' else 'float'}, {NT_SLOTS[best - base]}>",
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": n // args.steps,
+                    "flops_per_launch": prof.flops[best] / n,
+                    "all_conv_igemm_tflops": round(fam_fl / (fam_ms * 1e-3) / 1e12, 2) if fam_ms else None,
+                    "all_wgrad_tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms else None,
+                    "conv_ms_per_step": round(fam_ms / args.steps, 3), "wgrad_ms_per_step": round(wg_ms / args.steps, 3)}
+        out = {"metric": "frames/sec (480x640, T=3, HRNet MFCNet) fwd+bwd", "value": round(world * B * T * args.steps / dt, 2),
+               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"MFCNet T={T} RGB-only (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, fwd+bwd+Adam "
+                                      f"(BASELINE.json configs[2])", "width": args.width, "global_batch": world * B,
+                          "frames_per_clip": T, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5)},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.width, T, H, W)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

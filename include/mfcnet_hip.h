@@ -312,6 +312,16 @@ typedef struct {
 } mfc_op;
 /* runs ops[0..n); returns 0 or (-(1000*index) + status) of the first failing record */
 int mfc_program_run(const mfc_op* ops, int32_t n, void* stream);
+/* In-process kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
+ * While enabled, every conv forward/dgrad and wgrad launch is bracketed by two events; mfc_prof_collect
+ * synchronises and sums elapsed time, launches and algorithmic FLOPs per bucket.
+ * bucket = family*16 + dtype*8 + slot;  family 0 = conv_igemm (slot: NT index {1,2,3,4,6} -> 0..4),
+ * family 1 = conv_wgrad (slot: TPW index {8,16,28} -> 0..2).                                          */
+#define MFC_PROF_BUCKETS 32
+typedef struct { double ms[MFC_PROF_BUCKETS]; double flops[MFC_PROF_BUCKETS]; double bytes[MFC_PROF_BUCKETS]; int64_t launches[MFC_PROF_BUCKETS]; } mfc_prof_result;
+int mfc_prof_enable(int on);
+int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded events, fills `out`, clears the log */
+
 /* tuning switches: id 1 = use ds_read_b64_tr_b16 in the bf16 wgrad kernel (default 1) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */

@@ -74,5 +74,10 @@ __device__ inline void bilin_src(int dst, int in_size, int out_size, int& i0, in
     lam = s - (float)i0;
 }
 
+// event-based kernel timing (runtime.hip)
+extern int g_mfc_prof_on;
+void mfc_prof_before(hipStream_t st, int bucket, double flops, double bytes);
+void mfc_prof_after(hipStream_t st);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #define MFC_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return MFC_ERR_LAUNCH; } while (0)

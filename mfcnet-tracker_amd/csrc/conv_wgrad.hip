@@ -222,7 +222,14 @@ static int wgrad_launch(const WgradK& k, size_t lds, int Y, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, TPW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    if (g_mfc_prof_on) {
+        const int slot = TPW == 8 ? 0 : TPW == 16 ? 1 : 2;
+        const double flops = 2.0 * k.N * k.Hout * k.Wout * (double)k.Co16 * k.Ci16 * k.TA * k.TB;
+        const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_p + (double)k.N * k.Hout * k.Wout * k.Cout_p) * sizeof(T);
+        mfc_prof_before(st, 1 * 16 + (sizeof(T) == 2 ? 8 : 0) + slot, flops, bytes);
+    }
     hipLaunchKernelGGL((conv_wgrad_kernel<T, TPW, TR>), dim3(k.splits, Y), dim3(256), lds, st, k);
+    if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

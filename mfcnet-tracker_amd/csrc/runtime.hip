@@ -156,6 +156,41 @@ extern "C" int mfc_adam_step(float* p, const float* g, float* m, float* v, int64
     return MFC_OK;
 }
 
+// ------------------------------------------------------------------ event profiler
+#include <vector>
+int g_mfc_prof_on = 0;
+namespace {
+struct ProfRec { hipEvent_t a, b; int bucket; double flops, bytes; };
+std::vector<ProfRec> g_log;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}
+void mfc_prof_before(hipStream_t st, int bucket, double flops, double bytes) {
+    ProfRec r; r.a = get_event(); r.b = get_event(); r.bucket = bucket; r.flops = flops; r.bytes = bytes;
+    (void)hipEventRecord(r.a, st);
+    g_log.push_back(r);
+}
+void mfc_prof_after(hipStream_t st) { (void)hipEventRecord(g_log.back().b, st); }
+extern "C" int mfc_prof_enable(int on) { g_mfc_prof_on = on; return MFC_OK; }
+extern "C" int mfc_prof_collect(mfc_prof_result* out) {
+    if (!out) return MFC_ERR_INVALID_ARG;
+    for (int i = 0; i < MFC_PROF_BUCKETS; ++i) { out->ms[i] = 0; out->flops[i] = 0; out->bytes[i] = 0; out->launches[i] = 0; }
+    for (auto& r : g_log) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return MFC_ERR_LAUNCH;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        if (r.bucket >= 0 && r.bucket < MFC_PROF_BUCKETS) {
+            out->ms[r.bucket] += ms; out->flops[r.bucket] += r.flops; out->bytes[r.bucket] += r.bytes; out->launches[r.bucket] += 1;
+        }
+        g_pool.push_back(r.a); g_pool.push_back(r.b);
+    }
+    g_log.clear();
+    return MFC_OK;
+}
+
 // ------------------------------------------------------------------ program interpreter
 extern "C" int mfc_op_size(void) { return (int)sizeof(mfc_op); }
 extern "C" const char* mfc_version(void) { return "mfcnet_hip 0.1 (gfx950)"; }

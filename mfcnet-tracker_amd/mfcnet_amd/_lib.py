@@ -95,6 +95,10 @@ class LossDesc(C.Structure):
                 ("B", i32), ("nc", i32), ("H", i32), ("W", i32), ("w_nll", f32), ("w_jac", f32), ("grad_scale", f32)]
 
 
+class ProfResult(C.Structure):
+    _fields_ = [("ms", C.c_double * 32), ("flops", C.c_double * 32), ("bytes", C.c_double * 32), ("launches", C.c_int64 * 32)]
+
+
 class RawOp(C.Structure):
     _fields_ = [("a", u64), ("b", u64), ("c", u64), ("n", C.c_int64), ("i", i32 * 12)]
 
@@ -114,7 +118,7 @@ EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_co
            "mfc_bn_finalize", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_bwd", "mfc_adam_step", "mfc_program_run",
-           "mfc_set_flag", "mfc_op_size", "mfc_version"]
+           "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect"]
 
 
 class MfcError(RuntimeError):
@@ -147,6 +151,8 @@ def _load():
         getattr(lib, name).argtypes = [vp, vp]
     lib.mfc_conv2d_lds_bytes.argtypes = [vp]
     lib.mfc_set_flag.argtypes = [i32, i32]
+    lib.mfc_prof_enable.argtypes = [i32]
+    lib.mfc_prof_collect.argtypes = [vp]
     if lib.mfc_op_size() != C.sizeof(Op):
         raise MfcError(f"mfc_op size mismatch: library {lib.mfc_op_size()} vs python mirror {C.sizeof(Op)}")
     return lib

@@ -33,6 +33,9 @@ class _Node(nn.Module):
     def forward(self, *a, **k):
         raise NotImplementedError("sub-modules of the HIP model are parameter containers; call the top-level model")
 
+    def __getitem__(self, idx):          # nn.Sequential / nn.ModuleList style access: model.base_model.last_layer[3]
+        return self._modules[str(idx)]
+
 
 def _get_node(root: nn.Module, path: List[str]) -> nn.Module:
     m = root
@@ -203,9 +206,6 @@ class HRNetMultiHIP(nn.Module):
         plan.run_backward(gout)
         if old is not None:
             self._G.add_(old)
-        for e in self._entries:
-            if e.is_param:
-                pass
         for n, p in self.named_parameters():
             if p.grad is None:
                 off = self._poff[n]

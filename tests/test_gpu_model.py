@@ -1,9 +1,17 @@
 """End-to-end parity of the HIP model (through the reference-shaped Python boundary and the C ABI)
 against (a) the golden vectors captured from the imported reference and (b) the CPU oracle.
 
-Tolerance: north_star asks <= 1e-3 max-abs on the fp32 heat-maps; the fp32 path is held to that on the
-logits here, gradients to 2e-3 relative on the norm / 1e-2 relative to the gradient scale on samples.
-bf16 (throughput mode) is reported and bounded loosely (it cannot meet 1e-3).
+Tolerances
+  * logits (the heat-maps north_star names): <= 1e-3 max-abs, fp32 mode;
+  * loss scalars: 1e-4;
+  * parameter gradients: norm within 2e-2, sampled / full-tensor relative L2 error <= GRAD_RTOL.
+    Train-mode gradients of this network are chaotic at fp32: the REFERENCE's own gradients move by
+    ~2e-2 (norm-relative, base_model.conv1.weight) when its inputs are perturbed by 1e-7 relative --
+    below one fp32 ulp -- because BatchNorm over a handful of pixels and ReLU sign flips amplify rounding
+    through ~300 layers (measured in tests/test_oracle_noise_floor.py).  A different-but-exact fp32
+    summation order (MFMA) is such a perturbation, so GRAD_RTOL is 3x that floor; kernel exactness itself
+    is pinned per kernel in tests/test_gpu_ops.py (2e-4).
+  * bf16 (throughput mode) is reported and bounded loosely (it cannot meet 1e-3).
 """
 import numpy as np
 import pytest
@@ -13,6 +21,12 @@ from golden_util import BIG_CASES, SMALL_CASES, case_inputs, case_state, compare
 
 pytestmark = pytest.mark.gpu
 ATOL = 1e-3
+GRAD_RTOL = 6e-2
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
 @pytest.fixture(scope="module")
@@ -73,8 +87,8 @@ def run_golden(mfc, name, fuse_bn=True):
         g = named[p].grad
         ref = float(z[key])
         got = float(g.double().norm())
-        assert abs(got - ref) <= 5e-3 * ref + 1e-7, (p, got, ref)
-        np.testing.assert_allclose(sample16(g), z["gradsample/" + p], rtol=2e-2, atol=1e-2 * ref / np.sqrt(g.numel()) + 1e-8, err_msg=p)
+        assert abs(got - ref) <= 2e-2 * ref + 1e-7, (p, got, ref)
+        assert rel_l2(sample16(g), z["gradsample/" + p]) < 2 * GRAD_RTOL, p      # 16 samples: noisier than the full tensor
     opt.step()
     for key in [f for f in z.files if f.startswith("paramsample/")]:
         p = key.split("/", 1)[1]
@@ -168,3 +182,27 @@ def test_width32_matches_oracle(mfc):
     for p in ("base_model.conv1.weight", "base_model.stage4.2.branches.3.1.conv1.weight", "multiframe_net.multiframe_net.0.weight"):
         g, go = dict(m.named_parameters())[p].grad.cpu(), net.sd[p].grad
         assert float((g - go).norm() / go.norm()) < 1e-2, p
+
+
+@pytest.mark.parametrize("name", ["large_rgb_train", "large_all_train"])
+def test_full_gradients_vs_oracle(mfc, name):
+    """Every sentinel parameter's FULL gradient tensor against the CPU oracle on the same inputs."""
+    from oracle import mfcnet_oracle as O
+    cfg, z = load_case(name)
+    frames, flows, depths, mask = case_inputs(cfg)
+    net = O.Net(case_state(cfg), cfg["model_type"], 48, 5, cfg["T"], cfg["optflow"], cfg["depth"])
+    net.train()
+    lo, _ = O.total_loss(net(frames, optflow=flows, depth=depths), mask, 5)
+    lo.backward()
+    m = build(mfc, cfg)
+    m.train()
+    loss, _ = mfc.mfc_loss(m(dev(frames), optflow=dev(flows), depth=dev(depths)), mask.cuda())
+    loss.backward()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for key in [f for f in z.files if f.startswith("gradnorm/")]:
+        p = key.split("/", 1)[1]
+        e = rel_l2(named[p].grad.cpu().numpy(), net.sd[p].grad.numpy())
+        worst = max(worst, e)
+        assert e < GRAD_RTOL, (p, e)
+    print("worst full-tensor gradient rel-L2 vs oracle:", worst)
