@@ -9,6 +9,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  MUST precede the CDLL below: PyTorch bundles its own libamdhip64.so.7 (same soname as
+#                     /opt/rocm's); whichever loads first serves the whole process, and torch's allocations must
+#                     live in the same HIP runtime instance as our launches.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmfcnet_hip.so")
 
@@ -167,7 +171,6 @@ def check(rc: int, what: str = "mfc call"):
 
 
 def stream_ptr():
-    import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -87,8 +87,9 @@ def run_golden(mfc, name, fuse_bn=True):
         g = named[p].grad
         ref = float(z[key])
         got = float(g.double().norm())
-        assert abs(got - ref) <= 2e-2 * ref + 1e-7, (p, got, ref)
-        assert rel_l2(sample16(g), z["gradsample/" + p]) < 2 * GRAD_RTOL, p      # 16 samples: noisier than the full tensor
+        assert abs(got - ref) <= 2e-2 * ref + 1e-6, (p, got, ref)
+        if ref > 1e-6:      # (a conv bias feeding a train-mode BN has an exactly-zero gradient: only rounding noise there)
+            assert rel_l2(sample16(g), z["gradsample/" + p]) < 2 * GRAD_RTOL, p  # 16 samples: noisier than the full tensor
     opt.step()
     for key in [f for f in z.files if f.startswith("paramsample/")]:
         p = key.split("/", 1)[1]
@@ -141,24 +142,30 @@ def test_state_dict_roundtrip_and_errors(mfc):
 
 
 def test_bf16_mode_tracks_fp32(mfc):
-    """Throughput mode: bf16 storage / MFMA, fp32 accumulate + statistics.  Not a 1e-3 claim."""
-    cfg, z = load_case("large_rgb_train")
+    """Throughput mode: bf16 storage / MFMA, fp32 accumulate + statistics.  Not a 1e-3 claim: bf16 rounding
+    (2^-8 relative per stored activation) through ~300 layers; eval mode is held to 5 % of the logit scale, the
+    train step (chaotic at fp32 already, see module docstring) to loss / gradient-direction agreement."""
+    cfg = dict(name="bf16case", model_type="HRNetMulti-Large", T=3, optflow=False, depth=False, B=4, H=128, W=192, mode="train")
     frames, flows, depths, mask = case_inputs(cfg)
     outs = {}
     for dt in ("fp32", "bf16"):
         m = build(mfc, cfg, dtype=dt)
+        m.eval()
+        with torch.no_grad():
+            ye = m(dev(frames)).cpu()
         m.train()
         y = m(dev(frames))
         loss, _ = mfc.mfc_loss(y, mask.cuda())
         loss.backward()
-        outs[dt] = (y.detach().cpu(), float(loss), m.base_model.last_layer[3].weight.grad.clone().cpu(),
+        outs[dt] = (ye, y.detach().cpu(), float(loss), m.base_model.last_layer[3].weight.grad.clone().cpu(),
                     m.multiframe_net.multiframe_net[0].weight.grad.clone().cpu())
-    y32, l32, g32, h32 = outs["fp32"]
-    y16, l16, g16, h16 = outs["bf16"]
-    scale = float(y32.abs().max())
-    assert float((y16 - y32).abs().max()) < 0.15 * scale
-    assert abs(l16 - l32) < 0.02
+    e32, y32, l32, g32, h32 = outs["fp32"]
+    e16, y16, l16, g16, h16 = outs["bf16"]
     cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))
+    print("bf16 vs fp32: eval max diff", float((e16 - e32).abs().max()), "of scale", float(e32.abs().max()),
+          "| train logits cos", cos(y16, y32), "loss", l16, l32, "grad cos", cos(g16, g32), cos(h16, h32))
+    assert float((e16 - e32).abs().max()) < 0.05 * float(e32.abs().max())
+    assert cos(y16, y32) > 0.98 and abs(l16 - l32) < 0.02
     assert cos(g16, g32) > 0.9 and cos(h16, h32) > 0.9
 
 
@@ -181,7 +188,7 @@ def test_width32_matches_oracle(mfc):
     assert float((y.detach().cpu() - yo.detach()).abs().max()) < ATOL
     for p in ("base_model.conv1.weight", "base_model.stage4.2.branches.3.1.conv1.weight", "multiframe_net.multiframe_net.0.weight"):
         g, go = dict(m.named_parameters())[p].grad.cpu(), net.sd[p].grad
-        assert float((g - go).norm() / go.norm()) < 1e-2, p
+        assert float((g - go).norm() / go.norm()) < GRAD_RTOL, p
 
 
 @pytest.mark.parametrize("name", ["large_rgb_train", "large_all_train"])
@@ -202,6 +209,8 @@ def test_full_gradients_vs_oracle(mfc, name):
     worst = 0.0
     for key in [f for f in z.files if f.startswith("gradnorm/")]:
         p = key.split("/", 1)[1]
+        if float(z[key]) < 1e-6:
+            continue
         e = rel_l2(named[p].grad.cpu().numpy(), net.sd[p].grad.numpy())
         worst = max(worst, e)
         assert e < GRAD_RTOL, (p, e)
