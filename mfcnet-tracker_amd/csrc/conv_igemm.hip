@@ -1,16 +1,26 @@
 // Implicit-GEMM convolution on MFMA for gfx950 (forward, and data-gradient by re-use).
 //
-// One workgroup (4 waves) computes a tile of <=128 output pixels (a TH x TW patch of one image)
-// x NT*16 output channels.  The input halo patch of the tile is staged ONCE per channel chunk into
-// LDS (so the k*k taps re-read LDS, not L2/HBM), with the producer's BatchNorm-apply + ReLU fused
-// into the staging pass; packed weights are staged per tap row.  MFMA roles: A = weights
-// (rows = cout), B = pixels (cols = pixel), so each lane ends up with 4 consecutive output
-// channels of one pixel -> vector stores along the NHWC channel axis.
-//   bf16: v_mfma_f32_16x16x32_bf16, one k-step = 4 granules (32 channels), fp32 accumulate
-//   fp32: v_mfma_f32_16x16x4_f32,   one k-step = 1 granule  (4 channels), exact fp32
+// PERSISTENT, software-pipelined design:
+//   * a workgroup (4 waves, one per SIMD) owns a contiguous run of output tiles; a tile is a TH x TW patch
+//     of one image (<= 64*MT pixels) x NT*16 output channels; wave w computes MT 16-pixel m-tiles x NT n-tiles
+//     with v_mfma_f32_16x16x32_bf16 (bf16) or v_mfma_f32_16x16x4_f32 (exact fp32), fp32 accumulate;
+//   * work is flattened into STAGES = (tile, channel chunk, tap row).  Per stage the packed weights of that
+//     tap row/chunk are needed in LDS, per (tile, chunk) the input halo patch.  While stage s computes from
+//     LDS, the global loads of stage s+1 (weights, and the next patch when it changes) are already in flight
+//     into registers; they are written to the other weight buffer after the MFMAs, one barrier per stage.
+//     So HBM/L2 latency hides under MFMA work, across tile boundaries too;
+//   * the k*k taps re-read the halo patch from LDS, never from L2/HBM; the producer's BatchNorm-apply + ReLU
+//     is fused into the patch store (zero padding AFTER the transform);
+//   * MFMA roles: A = weights (rows = cout), B = pixels (cols = pixel): each lane ends with 4 consecutive
+//     output channels of one pixel -> 8/16-byte vector stores along the NHWC channel axis;
+//   * epilogue: + bias, optional accumulate, per-(group,channel) sum / sum-of-squares -> replica atomics.
+//   * block ids are remapped so that each XCD (private L2) owns a contiguous range of tiles.
 // Replaces: nn.Conv2d forward / cuDNN dgrad of models/hrnet.py:39-42,82-88,200-230,361-386,334-351
 // and models/multiframe_model.py:191-201 (see include/mfcnet_hip.h).
 #include "common.h"
+
+#define PMAX_OF(MT) ((MT) == 4 ? 6 : 10)   // max 16-byte patch pieces a thread prefetches per (tile, chunk)
+#define WMAX 6       // max 16-byte weight pieces a thread prefetches per stage
 
 struct ConvK {
     const char* in; const char* wp; char* out;
@@ -23,83 +33,104 @@ struct ConvK {
     int TH, TW, tilesY, tilesX;
     int KG, nchunks, Kg_total, Np;      // chunk granules, #chunks, packed K granules, packed N
     int PH, PW, pitch;                  // patch dims (pixels) and pixel pitch (bytes)
-    int Yblocks, nwg;
-    int off_w, off_ktab;                // LDS offsets (bytes)
+    int Yblocks, nunits, per_block;     // units = tiles x cout blocks; units per workgroup
+    int off_w0, off_w1, off_ktab, off_red;   // LDS offsets (bytes)
 };
 
-template <typename T, int NT>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
+template <typename T, int NT, int MT>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     constexpr int E = Gran<T>::E;
     constexpr bool BF = (E == 8);
     constexpr int NT16 = NT * 16;
+    constexpr int PMAX = PMAX_OF(MT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
-    char* wl = smem + p.off_w;
     int* ktab = (int*)(smem + p.off_ktab);
+    float* red = (float*)(smem + p.off_red);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L = xcd_remap(blockIdx.x, p.nwg);
-    const int yb = L % p.Yblocks;
-    int xt = L / p.Yblocks;
-    const int tx_i = xt % p.tilesX; xt /= p.tilesX;
-    const int ty_i = xt % p.tilesY;
-    const int n = xt / p.tilesY;
-    const int n0 = yb * NT16;
-    const int i0 = ty_i * p.TH, j0 = tx_i * p.TW;
-    const int ih0 = i0 * p.s + p.dh0, iw0 = j0 * p.s + p.dw0;
-    const int grp = n / p.ipg;
+    const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int u0 = Lb * p.per_block;
+    const int nun = min(p.per_block, p.nunits - u0);
+    if (nun <= 0) return;
+    const int SPT = p.nchunks * p.TA;
+    const int total = nun * SPT;
+    const int npix = p.PH * p.PW;
+    const int cq = (lane >> 4) * 4;
 
-    // this lane's two pixels (one per m-tile)
-    int pbase[2]; bool pvalid[2]; int pty[2], ptx[2];
+    // lane's pixels inside a tile (tile-shape dependent only)
+    int pbase[MT]; int pty[MT], ptx[MT]; bool pin[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        int pp = (wave * 2 + mt) * 16 + (lane & 15);
+    for (int mt = 0; mt < MT; ++mt) {
+        int pp = (wave * MT + mt) * 16 + (lane & 15);
         int ty = pp / p.TW, tx = pp - ty * p.TW;
-        bool v = (pp < p.TH * p.TW) && (i0 + ty < p.Hl) && (j0 + tx < p.Wl);
+        bool v = pp < p.TH * p.TW;
         if (!v) { ty = 0; tx = 0; }
-        pty[mt] = ty; ptx[mt] = tx; pvalid[mt] = v;
+        pty[mt] = ty; ptx[mt] = tx; pin[mt] = v;
         pbase[mt] = ((ty * p.s) * p.PW + tx * p.s) * p.pitch + (BF ? 0 : (lane >> 4) * 4);
     }
 
-    f32x4 acc[2][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int npix = p.PH * p.PW;
-    const size_t in_img = (size_t)n * p.Hin * p.Win;
+    // ---------------- prefetch state (registers) ----------------
+    uint4 preg[PMAX]; unsigned pmask = 0;
+    uint4 wreg[WMAX];
+    float sc[E], sh[E];
+    int p_kg = 0, p_gi = 0, p_KGP = 1, p_pstep = 256; bool p_xf = false;
+    int w_kg = 0;
 
-    for (int c = 0; c < p.nchunks; ++c) {
+    auto unit_coords = [&](int u, int& n, int& i0, int& j0, int& n0) {
+        const int yb = u % p.Yblocks; int xt = u / p.Yblocks;
+        const int txi = xt % p.tilesX; xt /= p.tilesX;
+        const int tyi = xt % p.tilesY; n = xt / p.tilesY;
+        i0 = tyi * p.TH; j0 = txi * p.TW; n0 = yb * NT16;
+    };
+
+    auto load_patch = [&](int u, int c) {
+        int n, i0, j0, n0; unit_coords(u, n, i0, j0, n0);
         const int g0 = c * p.KG;
         const int kg = min(p.KG, p.Cin_g - g0);
         int KGP = 1; while (KGP < kg) KGP <<= 1;
-        const int nslots = BF ? ((p.TB * kg + 3) & ~3) : p.TB * kg;
-        __syncthreads();                      // previous chunk fully consumed
-        if (tid < nslots) {                   // slot -> patch offset (tail slots repeat the last valid one)
-            int q = min(tid, p.TB * kg - 1);
-            int b = q / kg, gi = q - b * kg;
-            ktab[tid] = b * p.pitch + gi * 16;
-        }
-        {   // ---- stage the input patch, fused BN-apply + ReLU, zero padding ----
-            const int gi = tid & (KGP - 1);
-            const int pstep = 256 / KGP;
-            float sc[E], sh[E];
-            const bool xf = (p.in_coef != nullptr);
-            if (xf && gi < kg) {
-                const float* cf = p.in_coef + (size_t)grp * 4 * p.Cin_p + (g0 + gi) * E;
+        p_kg = kg; p_KGP = KGP; p_gi = tid & (KGP - 1); p_pstep = 256 / KGP;
+        p_xf = (p.in_coef != nullptr);
+        pmask = 0;
+        if (p_gi < kg) {
+            if (p_xf) {
+                const float* cf = p.in_coef + (size_t)(n / p.ipg) * 4 * p.Cin_p + (g0 + p_gi) * E;
 #pragma unroll
                 for (int e = 0; e < E; ++e) { sc[e] = cf[e]; sh[e] = cf[p.Cin_p + e]; }
             }
-            if (gi < kg) {
-                for (int pix = tid / KGP; pix < npix; pix += pstep) {
-                    int py = pix / p.PW, px = pix - py * p.PW;
-                    int ih = ih0 + py, iw = iw0 + px;
-                    uint4 v = make_uint4(0, 0, 0, 0);
+            const int ih0 = i0 * p.s + p.dh0, iw0 = j0 * p.s + p.dw0;
+            const char* base = p.in + (size_t)n * p.Hin * p.Win * p.Cin_p * sizeof(T) + (size_t)(g0 + p_gi) * 16;
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) {
+                const int pix = tid / KGP + i * p_pstep;
+                if (pix < npix) {
+                    const int py = pix / p.PW, px = pix - py * p.PW;
+                    const int ih = ih0 + py, iw = iw0 + px;
                     if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
-                        v = *(const uint4*)(p.in + ((in_img + (size_t)ih * p.Win + iw) * p.Cin_p) * sizeof(T) + (size_t)(g0 + gi) * 16);
-                        if (xf) {
+                        preg[i] = *(const uint4*)(base + ((size_t)ih * p.Win + iw) * p.Cin_p * sizeof(T));
+                        pmask |= 1u << i;
+                    }
+                }
+            }
+        }
+    };
+    auto store_patch = [&]() {
+        if (p_gi < p_kg) {
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) {
+                const int pix = tid / p_KGP + i * p_pstep;
+                if (pix < npix) {
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (pmask & (1u << i)) {
+                        v = preg[i];
+                        if (p_xf) {
                             float f[E];
                             Gran<T>::unpack(v, f);
 #pragma unroll
@@ -110,140 +141,214 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
                             v = Gran<T>::pack(f);
                         }
                     }
-                    *(uint4*)(patch + pix * p.pitch + gi * 16) = v;
+                    *(uint4*)(patch + pix * p.pitch + p_gi * 16) = v;
                 }
             }
         }
-        for (int a = 0; a < p.TA; ++a) {
-            if (a > 0) __syncthreads();       // previous tap row's weights consumed
-            // ---- stage packed weights of tap row a for this chunk: [slot][NT16][16B] ----
-            for (int b = 0; b < p.TB; ++b) {
-                const char* src = p.wp + ((size_t)((a * p.TB + b) * p.Kg_total + g0) * p.Np + n0) * 16;
-                for (int idx = tid; idx < kg * NT16; idx += 256) {
-                    int gi = idx / NT16, nn = idx - gi * NT16;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (n0 + nn < p.Np) v = *(const uint4*)(src + ((size_t)gi * p.Np + nn) * 16);
-                    *(uint4*)(wl + ((b * kg + gi) * NT16 + nn) * 16) = v;
+        // slot -> patch offset table for this chunk (tail slots repeat the last valid one; their weights are zero)
+        const int nslots = BF ? ((p.TB * p_kg + 3) & ~3) : p.TB * p_kg;
+        if (tid < nslots) {
+            int q = min(tid, p.TB * p_kg - 1);
+            int b = q / p_kg, gi = q - b * p_kg;
+            ktab[tid] = b * p.pitch + gi * 16;
+        }
+    };
+    auto load_w = [&](int u, int c, int a) {
+        const int n0 = (u % p.Yblocks) * NT16;
+        const int g0 = c * p.KG;
+        const int kg = min(p.KG, p.Cin_g - g0);
+        w_kg = kg;
+        const int cnt = p.TB * kg * NT16;
+#pragma unroll
+        for (int i = 0; i < WMAX; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < cnt) {
+                const int slot = idx / NT16, nn = idx - slot * NT16;
+                const int b = slot / kg, gi = slot - b * kg;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (n0 + nn < p.Np)
+                    v = *(const uint4*)(p.wp + ((size_t)((a * p.TB + b) * p.Kg_total + g0 + gi) * p.Np + n0 + nn) * 16);
+                wreg[i] = v;
+            }
+        }
+    };
+    auto store_w = [&](char* wl) {
+        const int cnt = p.TB * w_kg * NT16;
+        const int nslots = BF ? ((p.TB * w_kg + 3) & ~3) : p.TB * w_kg;
+#pragma unroll
+        for (int i = 0; i < WMAX; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < cnt) *(uint4*)(wl + idx * 16) = wreg[i];
+            else if (idx < nslots * NT16) *(uint4*)(wl + idx * 16) = make_uint4(0, 0, 0, 0);
+        }
+    };
+
+    // ---------------- prologue ----------------
+    load_patch(u0, 0);
+    load_w(u0, 0, 0);
+    store_patch();
+    store_w(smem + p.off_w0);
+    int cur_kg = p_kg;
+    __syncthreads();
+
+    int tl = 0, c = 0, a = 0;          // current stage coordinates
+    bool red_pending = false; int red_n0 = 0, red_grp = 0, red_rep = 0, red_par = 0;   // red is double-buffered by tile parity
+    for (int g = 0; g < total; ++g) {
+        const int u = u0 + tl;
+        // next stage coordinates
+        int tl2 = tl, c2 = c, a2 = a + 1;
+        if (a2 == p.TA) { a2 = 0; ++c2; if (c2 == p.nchunks) { c2 = 0; ++tl2; } }
+        const bool nxt = (g + 1 < total);
+        const bool newpatch = nxt && (a2 == 0);
+        if (red_pending) {             // statistics of the previous tile: LDS partials -> replica atomics
+            if (tid < 2 * NT16) {
+                const int which = tid / NT16, cl = tid - which * NT16;
+                if (red_n0 + cl < p.Cout_p) {
+                    const float* rd = red + (red_par ^ 1) * 8 * NT16;
+                    float s = rd[(0 * 2 + which) * NT16 + cl] + rd[(1 * 2 + which) * NT16 + cl] +
+                              rd[(2 * 2 + which) * NT16 + cl] + rd[(3 * 2 + which) * NT16 + cl];
+                    atomicAdd(p.out_stats + (((size_t)red_rep * p.G + red_grp) * 2 + which) * p.Cout_p + red_n0 + cl, s);
                 }
             }
-            for (int idx = p.TB * kg * NT16 + tid; idx < nslots * NT16; idx += 256)
-                *(uint4*)(wl + idx * 16) = make_uint4(0, 0, 0, 0);
-            __syncthreads();
+            red_pending = false;
+        }
+        if (nxt) load_w(u0 + tl2, c2, a2);
+        if (newpatch) load_patch(u0 + tl2, c2);
+
+        // ---------------- compute stage (tl, c, a) ----------------
+        {
+            const char* wl = smem + ((g & 1) ? p.off_w1 : p.off_w0);
+            const int nslots = BF ? ((p.TB * cur_kg + 3) & ~3) : p.TB * cur_kg;
             const int arow = a * p.PW * p.pitch;
             if constexpr (BF) {
                 const int nk = nslots >> 2;
                 for (int ks = 0; ks < nk; ++ks) {
                     const int q = ks * 4 + (lane >> 4);
-                    const int ko = ktab[q];
-                    bf16x8 xf0 = *(const bf16x8*)(patch + pbase[0] + arow + ko);
-                    bf16x8 xf1 = *(const bf16x8*)(patch + pbase[1] + arow + ko);
+                    const int ko = ktab[q] + arow;
+                    bf16x8 xf[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(patch + pbase[mt] + ko);
                     const char* wq = wl + (q * NT16 + (lane & 15)) * 16;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         bf16x8 wf = *(const bf16x8*)(wq + nt * 256);
-                        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf0, acc[0][nt], 0, 0, 0);
-                        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf1, acc[1][nt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mt], acc[mt][nt], 0, 0, 0);
                     }
                 }
             } else {
                 for (int q = 0; q < nslots; ++q) {
-                    const int ko = ktab[q];
-                    float x0 = *(const float*)(patch + pbase[0] + arow + ko);
-                    float x1 = *(const float*)(patch + pbase[1] + arow + ko);
+                    const int ko = ktab[q] + arow;
+                    float xv[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xv[mt] = *(const float*)(patch + pbase[mt] + ko);
                     const char* wq = wl + (q * NT16 + (lane & 15)) * 16 + (lane >> 4) * 4;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         float wf = *(const float*)(wq + nt * 256);
-                        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, x0, acc[0][nt], 0, 0, 0);
-                        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, x1, acc[1][nt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, xv[mt], acc[mt][nt], 0, 0, 0);
                     }
                 }
             }
         }
-    }
 
-    // ---------------- epilogue: bias, accumulate, store, statistics ----------------
-    const int cq = (lane >> 4) * 4;
-    float ssum[NT][4], ssq[NT][4];
+        // ---------------- tile epilogue ----------------
+        if (c == p.nchunks - 1 && a == p.TA - 1) {
+            int n, i0, j0, n0; unit_coords(u, n, i0, j0, n0);
+            float ssum[NT][4], ssq[NT][4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
+                for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int oi = (i0 + pty[mt]) * p.osh + p.ooh, oj = (j0 + ptx[mt]) * p.osw + p.oow;
-        char* orow = p.out + (((size_t)n * p.Hout + oi) * p.Wout + oj) * p.Cout_p * sizeof(T);
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool valid = pin[mt] && (i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl);
+                const int oi = (i0 + pty[mt]) * p.osh + p.ooh, oj = (j0 + ptx[mt]) * p.osw + p.oow;
+                T* orow = (T*)(p.out + (((size_t)n * p.Hout + oi) * p.Wout + oj) * p.Cout_p * sizeof(T));
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = n0 + nt * 16 + cq;
-            if (co >= p.Cout_p) continue;
-            float v[4];
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = n0 + nt * 16 + cq;
+                    float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[mt][nt][r];
-                if (p.bias && co + r < p.Cout) v[r] += p.bias[co + r];
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[mt][nt][r];
+                        acc[mt][nt][r] = 0.f;
+                        if (p.bias && co + r < p.Cout) v[r] += p.bias[co + r];
+                    }
+                    if (valid && co < p.Cout_p) {
+                        T* o = orow + co;
+                        if (p.accumulate) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += ld_elem<T>(o + r);
+                        }
+                        if constexpr (BF) {
+                            *(uint2*)o = make_uint2(bf16_bits(v[0]) | (bf16_bits(v[1]) << 16), bf16_bits(v[2]) | (bf16_bits(v[3]) << 16));
+                        } else {
+                            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ssum[nt][r] += v[r]; ssq[nt][r] += v[r] * v[r]; }
+                    }
+                }
             }
-            if (pvalid[mt]) {
-                T* o = (T*)orow + co;
-                if (p.accumulate) {
+            if (p.out_stats) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += ld_elem<T>(o + r);
-                }
-                if constexpr (BF) {
-                    uint2 pk = make_uint2(bf16_bits(v[0]) | (bf16_bits(v[1]) << 16), bf16_bits(v[2]) | (bf16_bits(v[3]) << 16));
-                    *(uint2*)o = pk;
-                } else {
-                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                }
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { ssum[nt][r] += v[r]; ssq[nt][r] += v[r] * v[r]; }
+                    for (int r = 0; r < 4; ++r) {
+                        float sa = wave16_sum(ssum[nt][r]);
+                        float sb = wave16_sum(ssq[nt][r]);
+                        if ((lane & 15) == 0) {
+                            red[red_par * 8 * NT16 + (wave * 2 + 0) * NT16 + nt * 16 + cq + r] = sa;
+                            red[red_par * 8 * NT16 + (wave * 2 + 1) * NT16 + nt * 16 + cq + r] = sb;
+                        }
+                    }
+                red_pending = true; red_n0 = n0; red_grp = n / p.ipg; red_rep = (u / p.Yblocks) % MFC_R; red_par ^= 1;
             }
         }
-    }
-    if (p.out_stats) {
-        __syncthreads();                      // LDS free for reuse
-        float* red = (float*)smem;            // [4 waves][2][NT16]
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = wave16_sum(ssum[nt][r]);
-                float b = wave16_sum(ssq[nt][r]);
-                if ((lane & 15) == 0) {
-                    red[(wave * 2 + 0) * NT16 + nt * 16 + cq + r] = a;
-                    red[(wave * 2 + 1) * NT16 + nt * 16 + cq + r] = b;
-                }
-            }
+
+        // ---------------- hand over to the next stage ----------------
+        if (nxt) store_w(smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
+        if (newpatch) {
+            __syncthreads();           // every wave has finished reading the current patch
+            store_patch();
+            cur_kg = p_kg;
+        }
         __syncthreads();
-        if (tid < 2 * NT16) {
-            const int which = tid / NT16, cl = tid - which * NT16;
-            if (n0 + cl < p.Cout_p) {
-                float s = red[(0 * 2 + which) * NT16 + cl] + red[(1 * 2 + which) * NT16 + cl] +
-                          red[(2 * 2 + which) * NT16 + cl] + red[(3 * 2 + which) * NT16 + cl];
-                const int rep = (blockIdx.x / p.Yblocks) % MFC_R;
-                atomicAdd(p.out_stats + (((size_t)rep * p.G + grp) * 2 + which) * p.Cout_p + n0 + cl, s);
-            }
+        tl = tl2; c = c2; a = a2;
+    }
+    if (red_pending && tid < 2 * NT16) {
+        const int which = tid / NT16, cl = tid - which * NT16;
+        if (red_n0 + cl < p.Cout_p) {
+            const float* rd = red + (red_par ^ 1) * 8 * NT16;
+            float s = rd[(0 * 2 + which) * NT16 + cl] + rd[(1 * 2 + which) * NT16 + cl] +
+                      rd[(2 * 2 + which) * NT16 + cl] + rd[(3 * 2 + which) * NT16 + cl];
+            atomicAdd(p.out_stats + (((size_t)red_rep * p.G + red_grp) * 2 + which) * p.Cout_p + red_n0 + cl, s);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-static void choose_tile(int Hl, int Wl, int& TH, int& TW) {
-    // maximise useful pixels per 128-pixel tile; prefer wide tiles (contiguous NHWC rows)
-    double best = -1; int bh = 8, bw = 16;
-    for (int tw = 1; tw <= 128 && tw <= Wl + 15; ++tw) {
-        int th = 128 / tw; if (th > Hl) th = Hl; if (th < 1) continue;
-        if (tw > Wl) continue;
+static void choose_tile(int Hl, int Wl, int cap, int& TH, int& TW, double& eff_out) {
+    // maximise useful pixels per tile of `cap` pixels; prefer wide / square-ish tiles
+    double best = -1; int bh = 1, bw = 1; double be = 0;
+    for (int tw = 1; tw <= cap && tw <= Wl; ++tw) {
+        int th = cap / tw; if (th > Hl) th = Hl; if (th < 1) continue;
         double tiles = (double)ceil_div(Hl, th) * ceil_div(Wl, tw);
-        double eff = (double)Hl * Wl / (tiles * 128.0);
-        double halo = (double)(th * tw) / ((th + 2.0) * (tw + 2.0));   // mild preference for square-ish
+        double eff = (double)Hl * Wl / (tiles * cap);
+        double halo = (double)(th * tw) / ((th + 2.0) * (tw + 2.0));
         double score = eff + 0.05 * halo + ((tw % 16 == 0) ? 0.01 : 0.0);
-        if (score > best) { best = score; bh = th; bw = tw; }
+        if (score > best) { best = score; bh = th; bw = tw; be = eff; }
     }
-    TH = bh; TW = bw;
+    TH = bh; TW = bw; eff_out = be;
 }
 
-static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, size_t& lds) {
+static int g_conv_num_cu = 256;
+
+static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, size_t& lds, int& grid) {
     if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
     if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
     const int E = d->dtype == MFC_BF16 ? 8 : 4;
@@ -258,15 +363,10 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, size_t& lds) {
     k.Hl = d->Hl; k.Wl = d->Wl; k.TA = d->TA; k.TB = d->TB; k.dh0 = d->dh0; k.dw0 = d->dw0; k.s = d->in_stride;
     k.osh = d->out_sh; k.osw = d->out_sw; k.ooh = d->out_oh; k.oow = d->out_ow;
     k.in_relu = d->in_relu; k.ipg = d->images_per_group; k.G = d->N / d->images_per_group; k.accumulate = d->accumulate;
-    k.TH = d->TH; k.TW = d->TW;
-    if (k.TH <= 0 || k.TW <= 0) choose_tile(d->Hl, d->Wl, k.TH, k.TW);
-    if (k.TH * k.TW > 128) return MFC_ERR_INVALID_ARG;
-    k.tilesY = ceil_div(d->Hl, k.TH); k.tilesX = ceil_div(d->Wl, k.TW);
     k.Kg_total = ceil_div(d->Cin, E);              // (packer and kernel agree on ceil(Cin/E))
     k.Np = ceil_div(d->Cout, 16) * 16;
     const int n16 = k.Np / 16;
-    // N tile: fewest computed n-tiles, mild preference for wide tiles (more reuse of the staged patch)
-    {
+    {   // N tile: fewest computed n-tiles, mild preference for wide tiles (more reuse of the staged patch)
         const int cand[5] = {6, 4, 3, 2, 1};
         double bestc = 1e30; NT = 1;
         for (int i = 0; i < 5; ++i) {
@@ -275,35 +375,63 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, size_t& lds) {
         }
     }
     k.Yblocks = ceil_div(n16, NT);
-    k.PH = (k.TH - 1) * k.s + k.TA; k.PW = (k.TW - 1) * k.s + k.TB;
-    // channel chunk: balanced chunks of <= 8 granules, shrunk until the LDS budget holds
-    int kgmax = 8;
-    for (;;) {
-        int nch = ceil_div(k.Cin_g, kgmax);
-        k.KG = ceil_div(k.Cin_g, nch); k.nchunks = ceil_div(k.Cin_g, k.KG);
-        k.pitch = k.KG * 16 + 16;
-        int nslots = (E == 8) ? ((k.TB * k.KG + 3) & ~3) : k.TB * k.KG;
-        size_t patch = (size_t)k.PH * k.PW * k.pitch;
-        size_t wbytes = (size_t)nslots * NT * 16 * 16;
-        k.off_w = (int)((patch + 15) & ~(size_t)15);
-        k.off_ktab = k.off_w + (int)wbytes;
-        lds = k.off_ktab + (size_t)nslots * 4 + 64;
-        size_t red = (size_t)4 * 2 * NT * 16 * 4;
-        if (lds < red) lds = red;
-        if (lds <= 64 * 1024 || kgmax == 1) break;
-        kgmax = (kgmax > 2) ? kgmax / 2 : 1;
+    // pixel tile: 256 pixels (4 m-tiles per wave: fewer LDS reads per MFMA) unless 128 covers the image better
+    // or the halo patch / prefetch registers do not fit
+    int cand_mt[2] = {4, 2};
+    bool ok = false;
+    for (int ci = 0; ci < 2 && !ok; ++ci) {
+        MT = cand_mt[ci];
+        if (MT == 4 && NT == 6) continue;      // 4x6 accumulator tiles + prefetch registers exceed 256 VGPRs (spills)
+        const int cap = 64 * MT;
+        if (d->TH > 0 && d->TW > 0) {
+            if (d->TH * d->TW > cap) continue;
+            if (MT == 4 && d->TH * d->TW <= 128) continue;
+            k.TH = d->TH; k.TW = d->TW;
+        } else {
+            double e4, e2; int th2, tw2;
+            choose_tile(d->Hl, d->Wl, cap, k.TH, k.TW, e4);
+            if (MT == 4) {
+                choose_tile(d->Hl, d->Wl, 128, th2, tw2, e2);
+                if (e2 > e4 * 1.08) continue;            // the smaller tile wastes clearly fewer MFMA rows
+                if (d->in_stride > 1) continue;          // strided patches are 4x larger: keep the 128-pixel tile
+            }
+        }
+        k.tilesY = ceil_div(d->Hl, k.TH); k.tilesX = ceil_div(d->Wl, k.TW);
+        k.PH = (k.TH - 1) * k.s + k.TA; k.PW = (k.TW - 1) * k.s + k.TB;
+        // channel chunk: balanced chunks of <= 8 granules, shrunk until LDS (<= 64 KiB -> 2 workgroups/CU) and the
+        // per-thread prefetch registers (PMAX / WMAX pieces) hold
+        for (int kgmax = 8; kgmax >= 1; kgmax = (kgmax > 2 ? kgmax / 2 : kgmax - 1)) {
+            const int nch = ceil_div(k.Cin_g, kgmax);
+            k.KG = ceil_div(k.Cin_g, nch); k.nchunks = ceil_div(k.Cin_g, k.KG);
+            k.pitch = k.KG * 16 + 16;
+            const int nslots = (E == 8) ? ((k.TB * k.KG + 3) & ~3) : k.TB * k.KG;
+            int KGP = 1; while (KGP < k.KG) KGP <<= 1;
+            const size_t patch = (size_t)k.PH * k.PW * k.pitch;
+            const size_t wbytes = (size_t)nslots * NT * 16 * 16;
+            k.off_w0 = (int)((patch + 15) & ~(size_t)15);
+            k.off_w1 = k.off_w0 + (int)wbytes;
+            k.off_ktab = k.off_w1 + (int)wbytes;
+            k.off_red = k.off_ktab + ((nslots * 4 + 15) & ~15);
+            lds = (size_t)k.off_red + (size_t)2 * 4 * 2 * NT * 16 * 4;
+            const bool regs_ok = ceil_div(k.PH * k.PW, 256 / KGP) <= PMAX_OF(MT) && ceil_div(nslots * NT * 16, 256) <= WMAX && nslots <= 256;
+            if (lds <= 64 * 1024 && regs_ok) { ok = true; break; }
+            if (kgmax == 1) break;
+        }
     }
-    if (lds > 160 * 1024) return MFC_ERR_UNSUPPORTED;
-    if (k.TB * k.KG > 256) return MFC_ERR_UNSUPPORTED;       // ktab is filled by one pass of 256 threads
-    k.nwg = k.N * k.tilesY * k.tilesX * k.Yblocks;
+    if (!ok) return MFC_ERR_UNSUPPORTED;
+    k.nunits = k.N * k.tilesY * k.tilesX * k.Yblocks;
+    grid = 2 * g_conv_num_cu;
+    if (grid > k.nunits) grid = k.nunits;
+    k.per_block = ceil_div(k.nunits, grid);
+    grid = ceil_div(k.nunits, k.per_block);
     return MFC_OK;
 }
 
-template <typename T, int NT>
-static int conv_launch(const ConvK& k, size_t lds, hipStream_t st) {
+template <typename T, int NT, int MT>
+static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on) {
@@ -313,25 +441,27 @@ static int conv_launch(const ConvK& k, size_t lds, hipStream_t st) {
         const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_g * 16.0) / (k.osh * k.osw) + (double)k.N * k.Hl * k.Wl * k.Cout_p * sizeof(T);
         mfc_prof_before(st, 0 * 16 + (sizeof(T) == 2 ? 8 : 0) + slot, flops, bytes);
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, NT>), dim3(k.nwg), dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT>), dim3(grid), dim3(256), lds, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
 
 extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
-    ConvK k; int NT; size_t lds;
-    int rc = conv_setup(d, k, NT, lds);
+    ConvK k; int NT, MT, grid; size_t lds;
+    int rc = conv_setup(d, k, NT, MT, lds, grid);
     return rc < 0 ? rc : (int)lds;
 }
 
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
-    ConvK k; int NT; size_t lds;
-    int rc = conv_setup(d, k, NT, lds);
+    ConvK k; int NT, MT, grid; size_t lds;
+    int rc = conv_setup(d, k, NT, MT, lds, grid);
     if (rc < 0) return rc;
     hipStream_t st = (hipStream_t)stream;
 #define MFC_CONV_CASE(nt) \
-    case nt: return d->dtype == MFC_BF16 ? conv_launch<bf16_t, nt>(k, lds, st) : conv_launch<float, nt>(k, lds, st);
+    case nt: \
+        if (d->dtype == MFC_BF16) return (MT == 4 && nt != 6) ? conv_launch<bf16_t, nt, (nt == 6 ? 2 : 4)>(k, lds, grid, st) : conv_launch<bf16_t, nt, 2>(k, lds, grid, st); \
+        return (MT == 4 && nt != 6) ? conv_launch<float, nt, (nt == 6 ? 2 : 4)>(k, lds, grid, st) : conv_launch<float, nt, 2>(k, lds, grid, st);
     switch (NT) {
         MFC_CONV_CASE(1) MFC_CONV_CASE(2) MFC_CONV_CASE(3) MFC_CONV_CASE(4) MFC_CONV_CASE(6)
     }
