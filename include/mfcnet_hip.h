@@ -74,7 +74,7 @@ typedef enum {
  * ------------------------------------------------------------------------------------ */
 typedef struct {
     const void* in;          /* T [N, Hin, Win, Cin_p] */
-    const void* wp;          /* T packed weights [TA*TB][Kg][Np16][granule] */
+    const void* wp;          /* T packed weights, layout of mfc_conv2d_layout(d) */
     void* out;               /* T [N, Hout, Wout, Cout_p] */
     const float* bias;       /* [>=Cout] or NULL */
     const float* in_coef;    /* [G][4][Cin_p] or NULL (no input transform) */
@@ -89,6 +89,11 @@ typedef struct {
     int32_t TH, TW;                        /* pixel tile (TH*TW <= 128); 0 = choose */
 } mfc_conv_desc;
 int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream);
+/* The packed weight image a launch of `d` reads is laid out [TA][nchunks][Yblocks][nslots][NT16][granule]: the
+ * weights of one (tap row, channel chunk, cout block) stage are one contiguous block that is DMA-copied
+ * straight into LDS.  The blocking depends on the launch geometry, so the packer asks for it here.      */
+typedef struct { int32_t KG, nchunks, NT16, Yblocks, nslots, TA, TB, lds_bytes; int64_t bytes; } mfc_conv_layout;
+int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
 /* LDS bytes a launch of `d` needs (for tests / planners); <0 on invalid desc. */
 int mfc_conv2d_lds_bytes(const mfc_conv_desc* d);
 
@@ -101,14 +106,13 @@ int mfc_conv2d_lds_bytes(const mfc_conv_desc* d);
  * ------------------------------------------------------------------------------------ */
 typedef struct {
     uint64_t src;            /* const float* [Cout][Cin][KH][KW] */
-    uint64_t dst;            /* T* [TA*TB][Kg][Np][granule] */
+    uint64_t dst;            /* T* [TA][nchunks][Yblocks][nslots][NT16][granule] (mfc_conv_layout of the consuming launch) */
     int32_t Cout, Cin, KH, KW;
     int32_t TA, TB, kh0, kh_step, kw0, kw_step;
     int32_t mode;            /* 0 fwd, 1 dgrad */
-    int32_t Kg, Np;          /* granules along k, padded n (multiple of 16) */
+    int32_t KG, nchunks, NT16, Yblocks, nslots;
     int32_t block0;          /* first block of this job in the launch (prefix sum) */
     int32_t nblocks;
-    int32_t pad_;
 } mfc_pack_job;
 int mfc_pack_weights(const mfc_pack_job* jobs_dev, int32_t njobs, int32_t total_blocks, int32_t dtype, void* stream);
 

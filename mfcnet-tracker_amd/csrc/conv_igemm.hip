@@ -19,8 +19,8 @@
 // and models/multiframe_model.py:191-201 (see include/mfcnet_hip.h).
 #include "common.h"
 
-#define PMAX_OF(MT) ((MT) == 4 ? 6 : 10)   // max 16-byte patch pieces a thread prefetches per (tile, chunk)
-#define WMAX 6       // max 16-byte weight pieces a thread prefetches per stage
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 struct ConvK {
     const char* in; const char* wp; char* out;
@@ -30,19 +30,28 @@ struct ConvK {
     int Hl, Wl, TA, TB, dh0, dw0, s;
     int osh, osw, ooh, oow;
     int in_relu, ipg, G, accumulate;
-    int TH, TW, tilesY, tilesX;
-    int KG, nchunks, Kg_total, Np;      // chunk granules, #chunks, packed K granules, packed N
+    int TH, TW, tilesY, tilesX, ntiles;
+    int KG, nchunks;                    // chunk granules (Cin_g % KG == 0), #chunks
     int PH, PW, pitch;                  // patch dims (pixels) and pixel pitch (bytes)
-    int Yblocks, nunits, per_block;     // units = tiles x cout blocks; units per workgroup
+    int Yblocks, nunits, per_block;     // units = cout blocks (slow) x tiles (fast); units per workgroup
+    int nslots, npieces, stage_bytes;   // weight slots per stage, 1-KiB DMA pieces per stage, bytes of one stage image
     int off_w0, off_w1, off_ktab, off_red;   // LDS offsets (bytes)
 };
 
-template <typename T, int NT, int MT>
+template <int CTRL> __device__ inline float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row (result in every lane): quad xor1, quad xor2, row_half_mirror, row_mirror
+__device__ inline float row16_sum(float v) {
+    v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v); v = dpp_add<0x140>(v);
+    return v;
+}
+
+template <typename T, int NT, int MT, int PMAX>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     constexpr int E = Gran<T>::E;
     constexpr bool BF = (E == 8);
     constexpr int NT16 = NT * 16;
-    constexpr int PMAX = PMAX_OF(MT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     int* ktab = (int*)(smem + p.off_ktab);
@@ -58,8 +67,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     const int total = nun * SPT;
     const int npix = p.PH * p.PW;
     const int cq = (lane >> 4) * 4;
+    const int kg = p.KG;
 
-    // lane's pixels inside a tile (tile-shape dependent only)
+    // ---------------- one-time per-thread tables (tile shape is fixed for the whole launch) ----------------
     int pbase[MT]; int pty[MT], ptx[MT]; bool pin[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -70,34 +80,46 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         pty[mt] = ty; ptx[mt] = tx; pin[mt] = v;
         pbase[mt] = ((ty * p.s) * p.PW + tx * p.s) * p.pitch + (BF ? 0 : (lane >> 4) * 4);
     }
+    // patch pieces this thread stages: granule p_gi of pixels tid/KGP + i*pstep  (py<<16|px, or -1)
+    int KGP = 1; while (KGP < kg) KGP <<= 1;
+    const int p_gi = tid & (KGP - 1), pstep = 256 / KGP;
+    int pyx[PMAX];
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) {
+        const int pix = tid / KGP + i * pstep;
+        const int py = pix / p.PW, px = pix - py * p.PW;
+        pyx[i] = (pix < npix && p_gi < kg) ? ((py << 16) | px) : -1;
+    }
+    // slot -> patch offset table (tail slots repeat the last valid one; their packed weights are zero)
+    if (tid < p.nslots) {
+        int q = min(tid, p.TB * kg - 1);
+        int b = q / kg, gi = q - b * kg;
+        ktab[tid] = b * p.pitch + gi * 16;
+    }
 
     f32x4 acc[MT][NT];
+    float ssum[NT][4], ssq[NT][4];          // running per-lane statistics partials (flushed when (group, cout block) changes)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
+    }
 
-    // ---------------- prefetch state (registers) ----------------
     uint4 preg[PMAX]; unsigned pmask = 0;
-    uint4 wreg[WMAX];
     float sc[E], sh[E];
-    int p_kg = 0, p_gi = 0, p_KGP = 1, p_pstep = 256; bool p_xf = false;
-    int w_kg = 0;
+    const bool p_xf = (p.in_coef != nullptr);
 
-    auto unit_coords = [&](int u, int& n, int& i0, int& j0, int& n0) {
-        const int yb = u % p.Yblocks; int xt = u / p.Yblocks;
+    auto unit_coords = [&](int u, int& n, int& i0, int& j0, int& yb) {     // cout block slowest, tiles fastest
+        yb = u / p.ntiles; int xt = u - yb * p.ntiles;
         const int txi = xt % p.tilesX; xt /= p.tilesX;
         const int tyi = xt % p.tilesY; n = xt / p.tilesY;
-        i0 = tyi * p.TH; j0 = txi * p.TW; n0 = yb * NT16;
+        i0 = tyi * p.TH; j0 = txi * p.TW;
     };
-
     auto load_patch = [&](int u, int c) {
-        int n, i0, j0, n0; unit_coords(u, n, i0, j0, n0);
-        const int g0 = c * p.KG;
-        const int kg = min(p.KG, p.Cin_g - g0);
-        int KGP = 1; while (KGP < kg) KGP <<= 1;
-        p_kg = kg; p_KGP = KGP; p_gi = tid & (KGP - 1); p_pstep = 256 / KGP;
-        p_xf = (p.in_coef != nullptr);
+        int n, i0, j0, yb; unit_coords(u, n, i0, j0, yb);
+        const int g0 = c * kg;
         pmask = 0;
         if (p_gi < kg) {
             if (p_xf) {
@@ -109,12 +131,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             const char* base = p.in + (size_t)n * p.Hin * p.Win * p.Cin_p * sizeof(T) + (size_t)(g0 + p_gi) * 16;
 #pragma unroll
             for (int i = 0; i < PMAX; ++i) {
-                const int pix = tid / KGP + i * p_pstep;
-                if (pix < npix) {
-                    const int py = pix / p.PW, px = pix - py * p.PW;
-                    const int ih = ih0 + py, iw = iw0 + px;
+                if (pyx[i] >= 0) {
+                    const int ih = ih0 + (pyx[i] >> 16), iw = iw0 + (pyx[i] & 0xffff);
                     if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
-                        preg[i] = *(const uint4*)(base + ((size_t)ih * p.Win + iw) * p.Cin_p * sizeof(T));
+                        preg[i] = *(const uint4*)(base + (size_t)(ih * p.Win + iw) * (p.Cin_p * (int)sizeof(T)));
                         pmask |= 1u << i;
                     }
                 }
@@ -122,127 +142,108 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         }
     };
     auto store_patch = [&]() {
-        if (p_gi < p_kg) {
 #pragma unroll
-            for (int i = 0; i < PMAX; ++i) {
-                const int pix = tid / p_KGP + i * p_pstep;
-                if (pix < npix) {
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (pmask & (1u << i)) {
-                        v = preg[i];
-                        if (p_xf) {
-                            float f[E];
-                            Gran<T>::unpack(v, f);
+        for (int i = 0; i < PMAX; ++i) {
+            if (pyx[i] >= 0) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (pmask & (1u << i)) {
+                    v = preg[i];
+                    if (p_xf) {
+                        float f[E];
+                        Gran<T>::unpack(v, f);
 #pragma unroll
-                            for (int e = 0; e < E; ++e) {
-                                float t = f[e] * sc[e] + sh[e];
-                                f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
-                            }
-                            v = Gran<T>::pack(f);
+                        for (int e = 0; e < E; ++e) {
+                            float t = f[e] * sc[e] + sh[e];
+                            f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
                         }
+                        v = Gran<T>::pack(f);
                     }
-                    *(uint4*)(patch + pix * p.pitch + p_gi * 16) = v;
+                }
+                *(uint4*)(patch + ((pyx[i] >> 16) * p.PW + (pyx[i] & 0xffff)) * p.pitch + p_gi * 16) = v;
+            }
+        }
+    };
+    // async global -> LDS copy of the packed weights of stage (a, c, cout block): the packed image is laid out
+    // [TA][nchunks][Yblocks][nslots][NT16][16 B], i.e. one stage is ONE contiguous block = the LDS image
+    auto dma_w = [&](int u, int c, int a, char* wl) {
+        const int yb = u / p.ntiles;
+        const char* src = p.wp + (size_t)((a * p.nchunks + c) * p.Yblocks + yb) * p.stage_bytes + lane * 16;
+        for (int piece = wave; piece < p.npieces; piece += 4)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + piece * 1024), (lds_void_t*)(wl + piece * 1024), 16, 0, 0);
+    };
+    // statistics: lanes -> row sums -> LDS (per wave) ; the cross-wave sum + atomics happen after the next barrier
+    int red_par = 0; bool red_pending = false; int red_n0 = 0, red_grp = 0, red_rep = 0;
+    auto stats_to_lds = [&](int n0, int grp, int rep) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sa = row16_sum(ssum[nt][r]), sb = row16_sum(ssq[nt][r]);
+                ssum[nt][r] = 0.f; ssq[nt][r] = 0.f;
+                if ((lane & 15) == 0) {
+                    red[red_par * 8 * NT16 + (wave * 2 + 0) * NT16 + nt * 16 + cq + r] = sa;
+                    red[red_par * 8 * NT16 + (wave * 2 + 1) * NT16 + nt * 16 + cq + r] = sb;
                 }
             }
-        }
-        // slot -> patch offset table for this chunk (tail slots repeat the last valid one; their weights are zero)
-        const int nslots = BF ? ((p.TB * p_kg + 3) & ~3) : p.TB * p_kg;
-        if (tid < nslots) {
-            int q = min(tid, p.TB * p_kg - 1);
-            int b = q / p_kg, gi = q - b * p_kg;
-            ktab[tid] = b * p.pitch + gi * 16;
-        }
+        red_pending = true; red_n0 = n0; red_grp = grp; red_rep = rep; red_par ^= 1;
     };
-    auto load_w = [&](int u, int c, int a) {
-        const int n0 = (u % p.Yblocks) * NT16;
-        const int g0 = c * p.KG;
-        const int kg = min(p.KG, p.Cin_g - g0);
-        w_kg = kg;
-        const int cnt = p.TB * kg * NT16;
-#pragma unroll
-        for (int i = 0; i < WMAX; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < cnt) {
-                const int slot = idx / NT16, nn = idx - slot * NT16;
-                const int b = slot / kg, gi = slot - b * kg;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (n0 + nn < p.Np)
-                    v = *(const uint4*)(p.wp + ((size_t)((a * p.TB + b) * p.Kg_total + g0 + gi) * p.Np + n0 + nn) * 16);
-                wreg[i] = v;
+    auto stats_flush = [&]() {
+        if (tid < 2 * NT16) {
+            const int which = tid / NT16, cl = tid - which * NT16;
+            if (red_n0 + cl < p.Cout_p) {
+                const float* rd = red + (red_par ^ 1) * 8 * NT16;
+                float s = rd[(0 * 2 + which) * NT16 + cl] + rd[(1 * 2 + which) * NT16 + cl] +
+                          rd[(2 * 2 + which) * NT16 + cl] + rd[(3 * 2 + which) * NT16 + cl];
+                atomicAdd(p.out_stats + (((size_t)red_rep * p.G + red_grp) * 2 + which) * p.Cout_p + red_n0 + cl, s);
             }
         }
-    };
-    auto store_w = [&](char* wl) {
-        const int cnt = p.TB * w_kg * NT16;
-        const int nslots = BF ? ((p.TB * w_kg + 3) & ~3) : p.TB * w_kg;
-#pragma unroll
-        for (int i = 0; i < WMAX; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < cnt) *(uint4*)(wl + idx * 16) = wreg[i];
-            else if (idx < nslots * NT16) *(uint4*)(wl + idx * 16) = make_uint4(0, 0, 0, 0);
-        }
+        red_pending = false;
     };
 
     // ---------------- prologue ----------------
+    dma_w(u0, 0, 0, smem + p.off_w0);
     load_patch(u0, 0);
-    load_w(u0, 0, 0);
     store_patch();
-    store_w(smem + p.off_w0);
-    int cur_kg = p_kg;
     __syncthreads();
 
     int tl = 0, c = 0, a = 0;          // current stage coordinates
-    bool red_pending = false; int red_n0 = 0, red_grp = 0, red_rep = 0, red_par = 0;   // red is double-buffered by tile parity
     for (int g = 0; g < total; ++g) {
         const int u = u0 + tl;
-        // next stage coordinates
         int tl2 = tl, c2 = c, a2 = a + 1;
         if (a2 == p.TA) { a2 = 0; ++c2; if (c2 == p.nchunks) { c2 = 0; ++tl2; } }
         const bool nxt = (g + 1 < total);
-        const bool newpatch = nxt && (a2 == 0);
-        if (red_pending) {             // statistics of the previous tile: LDS partials -> replica atomics
-            if (tid < 2 * NT16) {
-                const int which = tid / NT16, cl = tid - which * NT16;
-                if (red_n0 + cl < p.Cout_p) {
-                    const float* rd = red + (red_par ^ 1) * 8 * NT16;
-                    float s = rd[(0 * 2 + which) * NT16 + cl] + rd[(1 * 2 + which) * NT16 + cl] +
-                              rd[(2 * 2 + which) * NT16 + cl] + rd[(3 * 2 + which) * NT16 + cl];
-                    atomicAdd(p.out_stats + (((size_t)red_rep * p.G + red_grp) * 2 + which) * p.Cout_p + red_n0 + cl, s);
-                }
-            }
-            red_pending = false;
-        }
-        if (nxt) load_w(u0 + tl2, c2, a2);
+        const bool newpatch = nxt && (a2 == 0) && (p.nchunks > 1 || tl2 != tl);
+        if (nxt) dma_w(u0 + tl2, c2, a2, smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
         if (newpatch) load_patch(u0 + tl2, c2);
+        if (red_pending) stats_flush();
 
         // ---------------- compute stage (tl, c, a) ----------------
         {
             const char* wl = smem + ((g & 1) ? p.off_w1 : p.off_w0);
-            const int nslots = BF ? ((p.TB * cur_kg + 3) & ~3) : p.TB * cur_kg;
-            const int arow = a * p.PW * p.pitch;
+            const char* pa = patch + a * p.PW * p.pitch;
             if constexpr (BF) {
-                const int nk = nslots >> 2;
+                const int nk = p.nslots >> 2;
+                const int gl = lane >> 4;
+                const char* wlb = wl + (gl * NT16 + (lane & 15)) * 16;
                 for (int ks = 0; ks < nk; ++ks) {
-                    const int q = ks * 4 + (lane >> 4);
-                    const int ko = ktab[q] + arow;
-                    bf16x8 xf[MT];
+                    const int kq = ktab[ks * 4 + gl];
+                    bf16x8 xf[MT], wf[NT];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(patch + pbase[mt] + ko);
-                    const char* wq = wl + (q * NT16 + (lane & 15)) * 16;
+                    for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(pa + pbase[mt] + kq);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        bf16x8 wf = *(const bf16x8*)(wq + nt * 256);
+                    for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(wlb + ks * (4 * NT16 * 16) + nt * 256);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mt], acc[mt][nt], 0, 0, 0);
-                    }
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
                 }
             } else {
-                for (int q = 0; q < nslots; ++q) {
-                    const int ko = ktab[q] + arow;
+                for (int q = 0; q < p.nslots; ++q) {
+                    const int ko = ktab[q];
                     float xv[MT];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) xv[mt] = *(const float*)(patch + pbase[mt] + ko);
+                    for (int mt = 0; mt < MT; ++mt) xv[mt] = *(const float*)(pa + pbase[mt] + ko);
                     const char* wq = wl + (q * NT16 + (lane & 15)) * 16 + (lane >> 4) * 4;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
@@ -257,12 +258,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 
         // ---------------- tile epilogue ----------------
         if (c == p.nchunks - 1 && a == p.TA - 1) {
-            int n, i0, j0, n0; unit_coords(u, n, i0, j0, n0);
-            float ssum[NT][4], ssq[NT][4];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
+            int n, i0, j0, yb; unit_coords(u, n, i0, j0, yb);
+            const int n0 = yb * NT16;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool valid = pin[mt] && (i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl);
@@ -276,7 +273,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                     for (int r = 0; r < 4; ++r) {
                         v[r] = acc[mt][nt][r];
                         acc[mt][nt][r] = 0.f;
-                        if (p.bias && co + r < p.Cout) v[r] += p.bias[co + r];
+                    }
+                    if (p.bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (co + r < p.Cout) v[r] += p.bias[co + r];
                     }
                     if (valid && co < p.Cout_p) {
                         T* o = orow + co;
@@ -289,46 +289,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                         } else {
                             *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
                         }
+                        if (p.out_stats) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { ssum[nt][r] += v[r]; ssq[nt][r] += v[r] * v[r]; }
+                            for (int r = 0; r < 4; ++r) { ssum[nt][r] += v[r]; ssq[nt][r] += v[r] * v[r]; }
+                        }
                     }
                 }
             }
             if (p.out_stats) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float sa = wave16_sum(ssum[nt][r]);
-                        float sb = wave16_sum(ssq[nt][r]);
-                        if ((lane & 15) == 0) {
-                            red[red_par * 8 * NT16 + (wave * 2 + 0) * NT16 + nt * 16 + cq + r] = sa;
-                            red[red_par * 8 * NT16 + (wave * 2 + 1) * NT16 + nt * 16 + cq + r] = sb;
-                        }
-                    }
-                red_pending = true; red_n0 = n0; red_grp = n / p.ipg; red_rep = (u / p.Yblocks) % MFC_R; red_par ^= 1;
+                // flush the running sums when the next unit belongs to another (statistic group, cout block) or the run ends
+                bool flush = (tl + 1 >= nun);
+                if (!flush) {
+                    int n2, i2, j2, yb2; unit_coords(u + 1, n2, i2, j2, yb2);
+                    flush = (yb2 != yb) || (n2 / p.ipg != n / p.ipg);
+                }
+                if (flush) stats_to_lds(n0, n / p.ipg, (u + blockIdx.x) % MFC_R);
             }
         }
 
         // ---------------- hand over to the next stage ----------------
-        if (nxt) store_w(smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
         if (newpatch) {
             __syncthreads();           // every wave has finished reading the current patch
             store_patch();
-            cur_kg = p_kg;
         }
-        __syncthreads();
+        __syncthreads();               // (drains the weight DMA of stage g+1: vmcnt(0) precedes the barrier)
         tl = tl2; c = c2; a = a2;
     }
-    if (red_pending && tid < 2 * NT16) {
-        const int which = tid / NT16, cl = tid - which * NT16;
-        if (red_n0 + cl < p.Cout_p) {
-            const float* rd = red + (red_par ^ 1) * 8 * NT16;
-            float s = rd[(0 * 2 + which) * NT16 + cl] + rd[(1 * 2 + which) * NT16 + cl] +
-                      rd[(2 * 2 + which) * NT16 + cl] + rd[(3 * 2 + which) * NT16 + cl];
-            atomicAdd(p.out_stats + (((size_t)red_rep * p.G + red_grp) * 2 + which) * p.Cout_p + red_n0 + cl, s);
-        }
-    }
+    if (red_pending) stats_flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -348,7 +335,7 @@ static void choose_tile(int Hl, int Wl, int cap, int& TH, int& TW, double& eff_o
 
 static int g_conv_num_cu = 256;
 
-static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, size_t& lds, int& grid) {
+static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid) {
     if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
     if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
     const int E = d->dtype == MFC_BF16 ? 8 : 4;
@@ -363,9 +350,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, size_t
     k.Hl = d->Hl; k.Wl = d->Wl; k.TA = d->TA; k.TB = d->TB; k.dh0 = d->dh0; k.dw0 = d->dw0; k.s = d->in_stride;
     k.osh = d->out_sh; k.osw = d->out_sw; k.ooh = d->out_oh; k.oow = d->out_ow;
     k.in_relu = d->in_relu; k.ipg = d->images_per_group; k.G = d->N / d->images_per_group; k.accumulate = d->accumulate;
-    k.Kg_total = ceil_div(d->Cin, E);              // (packer and kernel agree on ceil(Cin/E))
-    k.Np = ceil_div(d->Cout, 16) * 16;
-    const int n16 = k.Np / 16;
+    const int n16 = ceil_div(d->Cout, 16);
     {   // N tile: fewest computed n-tiles, mild preference for wide tiles (more reuse of the staged patch)
         const int cand[5] = {6, 4, 3, 2, 1};
         double bestc = 1e30; NT = 1;
@@ -381,7 +366,6 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, size_t
     bool ok = false;
     for (int ci = 0; ci < 2 && !ok; ++ci) {
         MT = cand_mt[ci];
-        if (MT == 4 && NT == 6) continue;      // 4x6 accumulator tiles + prefetch registers exceed 256 VGPRs (spills)
         const int cap = 64 * MT;
         if (d->TH > 0 && d->TW > 0) {
             if (d->TH * d->TW > cap) continue;
@@ -398,28 +382,34 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, size_t
         }
         k.tilesY = ceil_div(d->Hl, k.TH); k.tilesX = ceil_div(d->Wl, k.TW);
         k.PH = (k.TH - 1) * k.s + k.TA; k.PW = (k.TW - 1) * k.s + k.TB;
-        // channel chunk: balanced chunks of <= 8 granules, shrunk until LDS (<= 64 KiB -> 2 workgroups/CU) and the
-        // per-thread prefetch registers (PMAX / WMAX pieces) hold
-        for (int kgmax = 8; kgmax >= 1; kgmax = (kgmax > 2 ? kgmax / 2 : kgmax - 1)) {
-            const int nch = ceil_div(k.Cin_g, kgmax);
-            k.KG = ceil_div(k.Cin_g, nch); k.nchunks = ceil_div(k.Cin_g, k.KG);
-            k.pitch = k.KG * 16 + 16;
-            const int nslots = (E == 8) ? ((k.TB * k.KG + 3) & ~3) : k.TB * k.KG;
-            int KGP = 1; while (KGP < k.KG) KGP <<= 1;
+        // channel chunk: the largest divisor of Cin_g (<= 8 granules) whose LDS image fits 64 KiB (-> 2 workgroups/CU)
+        // and whose staging fits the per-thread piece budgets
+        for (int kg = (k.Cin_g < 8 ? k.Cin_g : 8); kg >= 1; --kg) {
+            if (k.Cin_g % kg) continue;
+            k.KG = kg; k.nchunks = k.Cin_g / kg;
+            // pixel pitch in 16-B slots: smallest P >= kg with P % 4 == 2 -> conflict-free ds_read_b128 fragment reads
+            int P = kg; while (P % 4 != 2) ++P;
+            if (E == 4) P = kg + 1;
+            k.pitch = P * 16;
+            k.nslots = (E == 8) ? ((k.TB * kg + 3) & ~3) : k.TB * kg;
+            int KGP = 1; while (KGP < kg) KGP <<= 1;
             const size_t patch = (size_t)k.PH * k.PW * k.pitch;
-            const size_t wbytes = (size_t)nslots * NT * 16 * 16;
-            k.off_w0 = (int)((patch + 15) & ~(size_t)15);
+            const size_t wbytes = ((size_t)k.nslots * NT * 16 * 16 + 1023) & ~(size_t)1023;
+            k.npieces = (int)(wbytes / 1024);
+            k.stage_bytes = k.nslots * NT * 16 * 16;
+            k.off_w0 = (int)((patch + 1023) & ~(size_t)1023);
             k.off_w1 = k.off_w0 + (int)wbytes;
             k.off_ktab = k.off_w1 + (int)wbytes;
-            k.off_red = k.off_ktab + ((nslots * 4 + 15) & ~15);
+            k.off_red = k.off_ktab + ((k.nslots * 4 + 15) & ~15);
             lds = (size_t)k.off_red + (size_t)2 * 4 * 2 * NT * 16 * 4;
-            const bool regs_ok = ceil_div(k.PH * k.PW, 256 / KGP) <= PMAX_OF(MT) && ceil_div(nslots * NT * 16, 256) <= WMAX && nslots <= 256;
+            PM = ceil_div(k.PH * k.PW, 256 / KGP);
+            const bool regs_ok = PM <= (MT == 4 ? 6 : 10) && k.nslots <= 256;
             if (lds <= 64 * 1024 && regs_ok) { ok = true; break; }
-            if (kgmax == 1) break;
         }
     }
     if (!ok) return MFC_ERR_UNSUPPORTED;
-    k.nunits = k.N * k.tilesY * k.tilesX * k.Yblocks;
+    k.ntiles = k.N * k.tilesY * k.tilesX;
+    k.nunits = k.ntiles * k.Yblocks;
     grid = 2 * g_conv_num_cu;
     if (grid > k.nunits) grid = k.nunits;
     k.per_block = ceil_div(k.nunits, grid);
@@ -427,11 +417,11 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, size_t
     return MFC_OK;
 }
 
-template <typename T, int NT, int MT>
+template <typename T, int NT, int MT, int PMAX>
 static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT, MT, PMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on) {
@@ -441,27 +431,49 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
         const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_g * 16.0) / (k.osh * k.osw) + (double)k.N * k.Hl * k.Wl * k.Cout_p * sizeof(T);
         mfc_prof_before(st, 0 * 16 + (sizeof(T) == 2 ? 8 : 0) + slot, flops, bytes);
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT>), dim3(grid), dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT, PMAX>), dim3(grid), dim3(256), lds, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
 
+extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
+    ConvK k; int NT, MT, PM, grid; size_t lds;
+    mfc_conv_desc t = *d;
+    if (!t.in) t.in = (const void*)16;
+    if (!t.wp) t.wp = (const void*)16;
+    if (!t.out) t.out = (void*)16;
+    int rc = conv_setup(&t, k, NT, MT, PM, lds, grid);
+    if (rc < 0 || !out) return rc < 0 ? rc : MFC_ERR_INVALID_ARG;
+    out->KG = k.KG; out->nchunks = k.nchunks; out->NT16 = NT * 16; out->Yblocks = k.Yblocks; out->nslots = k.nslots;
+    out->TA = k.TA; out->TB = k.TB; out->lds_bytes = (int32_t)lds;
+    out->bytes = (int64_t)k.TA * k.nchunks * k.Yblocks * k.stage_bytes;
+    return MFC_OK;
+}
+
 extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
-    ConvK k; int NT, MT, grid; size_t lds;
-    int rc = conv_setup(d, k, NT, MT, lds, grid);
+    ConvK k; int NT, MT, PM, grid; size_t lds;
+    int rc = conv_setup(d, k, NT, MT, PM, lds, grid);
     return rc < 0 ? rc : (int)lds;
 }
 
+template <typename T, int NT>
+static int conv_dispatch(const ConvK& k, int MT, int PM, size_t lds, int grid, hipStream_t st) {
+    if (MT == 4) {
+        if (PM <= 6) return conv_launch<T, NT, 4, 6>(k, lds, grid, st);
+        return MFC_ERR_UNSUPPORTED;
+    }
+    if (PM <= 4) return conv_launch<T, NT, 2, 4>(k, lds, grid, st);
+    return conv_launch<T, NT, 2, 10>(k, lds, grid, st);
+}
+
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
-    ConvK k; int NT, MT, grid; size_t lds;
-    int rc = conv_setup(d, k, NT, MT, lds, grid);
+    ConvK k; int NT, MT, PM, grid; size_t lds;
+    int rc = conv_setup(d, k, NT, MT, PM, lds, grid);
     if (rc < 0) return rc;
     hipStream_t st = (hipStream_t)stream;
 #define MFC_CONV_CASE(nt) \
-    case nt: \
-        if (d->dtype == MFC_BF16) return (MT == 4 && nt != 6) ? conv_launch<bf16_t, nt, (nt == 6 ? 2 : 4)>(k, lds, grid, st) : conv_launch<bf16_t, nt, 2>(k, lds, grid, st); \
-        return (MT == 4 && nt != 6) ? conv_launch<float, nt, (nt == 6 ? 2 : 4)>(k, lds, grid, st) : conv_launch<float, nt, 2>(k, lds, grid, st);
+    case nt: return d->dtype == MFC_BF16 ? conv_dispatch<bf16_t, nt>(k, MT, PM, lds, grid, st) : conv_dispatch<float, nt>(k, MT, PM, lds, grid, st);
     switch (NT) {
         MFC_CONV_CASE(1) MFC_CONV_CASE(2) MFC_CONV_CASE(3) MFC_CONV_CASE(4) MFC_CONV_CASE(6)
     }

@@ -17,21 +17,25 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const mfc_pack_job* jobs, int njobs) {
     constexpr int E = Gran<T>::E;
     const mfc_pack_job j = jobs[find_job(jobs, njobs, blockIdx.x)];
-    const long total = (long)j.TA * j.TB * j.Kg * j.Np;
+    const long total = (long)j.TA * j.nchunks * j.Yblocks * j.nslots * j.NT16;
     long idx = (long)(blockIdx.x - j.block0) * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int n = (int)(idx % j.Np); long r = idx / j.Np;
-    const int g = (int)(r % j.Kg); const int tap = (int)(r / j.Kg);
-    const int a = tap / j.TB, b = tap - a * j.TB;
+    const int nn = (int)(idx % j.NT16); long r = idx / j.NT16;
+    const int slot = (int)(r % j.nslots); r /= j.nslots;
+    const int yb = (int)(r % j.Yblocks); r /= j.Yblocks;
+    const int c = (int)(r % j.nchunks); const int a = (int)(r / j.nchunks);
+    const int b = slot / j.KG, gi = slot - b * j.KG;
+    const bool sv = slot < j.TB * j.KG;
     const int kh = j.kh0 + a * j.kh_step, kw = j.kw0 + b * j.kw_step;
+    const int n = yb * j.NT16 + nn;
     const float* src = (const float*)j.src;
     float f[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int k = g * E + e;
+        const int k = (c * j.KG + gi) * E + e;
         int co, ci;
         if (j.mode == 0) { co = n; ci = k; } else { co = k; ci = n; }
-        f[e] = (co < j.Cout && ci < j.Cin) ? src[(((size_t)co * j.Cin + ci) * j.KH + kh) * j.KW + kw] : 0.f;
+        f[e] = (sv && co < j.Cout && ci < j.Cin) ? src[(((size_t)co * j.Cin + ci) * j.KH + kh) * j.KW + kw] : 0.f;
     }
     ((uint4*)j.dst)[idx] = Gran<T>::pack(f);
 }

@@ -38,7 +38,13 @@ class ConvDesc(C.Structure):
 class PackJob(C.Structure):
     _fields_ = [("src", u64), ("dst", u64), ("Cout", i32), ("Cin", i32), ("KH", i32), ("KW", i32),
                 ("TA", i32), ("TB", i32), ("kh0", i32), ("kh_step", i32), ("kw0", i32), ("kw_step", i32),
-                ("mode", i32), ("Kg", i32), ("Np", i32), ("block0", i32), ("nblocks", i32), ("pad_", i32)]
+                ("mode", i32), ("KG", i32), ("nchunks", i32), ("NT16", i32), ("Yblocks", i32), ("nslots", i32),
+                ("block0", i32), ("nblocks", i32)]
+
+
+class ConvLayout(C.Structure):
+    _fields_ = [("KG", i32), ("nchunks", i32), ("NT16", i32), ("Yblocks", i32), ("nslots", i32), ("TA", i32), ("TB", i32),
+                ("lds_bytes", i32), ("bytes", C.c_int64)]
 
 
 class WgradDesc(C.Structure):
@@ -118,7 +124,7 @@ class Op(C.Structure):
 
 
 # every symbol include/mfcnet_hip.h declares
-EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_unpack_wgrad",
+EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_unpack_wgrad",
            "mfc_bn_finalize", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_bwd", "mfc_adam_step", "mfc_program_run",
@@ -154,6 +160,7 @@ def _load():
                  "mfc_loss_bwd"):
         getattr(lib, name).argtypes = [vp, vp]
     lib.mfc_conv2d_lds_bytes.argtypes = [vp]
+    lib.mfc_conv2d_layout.argtypes = [vp, vp]
     lib.mfc_set_flag.argtypes = [i32, i32]
     lib.mfc_prof_enable.argtypes = [i32]
     lib.mfc_prof_collect.argtypes = [vp]
@@ -176,3 +183,14 @@ def stream_ptr():
 
 def call(fn, desc, what=None):
     check(fn(C.byref(desc), stream_ptr()), what or fn.__name__)
+
+
+def conv_layout(desc: ConvDesc) -> ConvLayout:
+    """Blocking of the packed weight image the launch described by `desc` will read."""
+    lay = ConvLayout()
+    check(lib.mfc_conv2d_layout(C.byref(desc), C.byref(lay)), "mfc_conv2d_layout")
+    return lay
+
+
+def pack_job_fields(lay: ConvLayout) -> dict:
+    return dict(KG=lay.KG, nchunks=lay.nchunks, NT16=lay.NT16, Yblocks=lay.Yblocks, nslots=lay.nslots)

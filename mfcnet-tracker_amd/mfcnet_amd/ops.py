@@ -47,7 +47,8 @@ def _run_jobs(jobs, cls, fn, *extra):
     for i, j in enumerate(jobs):
         for k, v in j.items():
             setattr(arr[i], k, v)
-        total = j["TA"] * j["TB"] * j["Kg"] * j["Np"] if cls is L.PackJob else j["Cout"] * j["Cin"] * j["KH"] * j["KW"]
+        total = (j["TA"] * j["nchunks"] * j["Yblocks"] * j["nslots"] * j["NT16"] if cls is L.PackJob
+                 else j["Cout"] * j["Cin"] * j["KH"] * j["KW"])
         arr[i].block0, arr[i].nblocks = b0, -(-total // 256)
         b0 += arr[i].nblocks
     dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
@@ -61,23 +62,25 @@ def s2_class(k, pad, ph):
     return khmax // 2 + 1, khmax, (ph + pad - khmax) // 2
 
 
-def pack_weight(w: torch.Tensor, dtype, mode="fwd", cls=(0, 0)) -> torch.Tensor:
-    """w: fp32 [Cout,Cin,k,k] on cuda.  mode: 'fwd' | 'dgrad' (stride 1) | 'dgrad_s2' (parity class cls)."""
+def pack_weight(w: torch.Tensor, desc: L.ConvDesc, mode="fwd", cls=(0, 0)) -> torch.Tensor:
+    """Pack fp32 [Cout,Cin,k,k] weights (cuda) into the image the launch `desc` reads.
+    mode: 'fwd' | 'dgrad' (stride 1) | 'dgrad_s2' (output parity class cls)."""
     Cout, Cin, k, _ = w.shape
-    E = 8 if dtype == torch.bfloat16 else 4
     pad = k // 2
+    lay = L.conv_layout(desc)
     if mode == "fwd":
-        TA = TB = k
-        j = dict(TA=k, TB=k, kh0=0, kh_step=1, kw0=0, kw_step=1, mode=0, Kg=-(-Cin // E), Np=rup(Cout, 16))
+        j = dict(TA=k, TB=k, kh0=0, kh_step=1, kw0=0, kw_step=1, mode=0)
     elif mode == "dgrad":
-        j = dict(TA=k, TB=k, kh0=k - 1, kh_step=-1, kw0=k - 1, kw_step=-1, mode=1, Kg=-(-Cout // E), Np=rup(Cin, 16))
+        j = dict(TA=k, TB=k, kh0=k - 1, kh_step=-1, kw0=k - 1, kw_step=-1, mode=1)
     else:
         ta, kh0, _ = s2_class(k, pad, cls[0])
         tb, kw0, _ = s2_class(k, pad, cls[1])
-        j = dict(TA=ta, TB=tb, kh0=kh0, kh_step=-2, kw0=kw0, kw_step=-2, mode=1, Kg=-(-Cout // E), Np=rup(Cin, 16))
-    out = torch.empty(j["TA"] * j["TB"] * j["Kg"] * j["Np"] * 16, dtype=torch.uint8, device="cuda")
+        j = dict(TA=ta, TB=tb, kh0=kh0, kh_step=-2, kw0=kw0, kw_step=-2, mode=1)
+    assert (j["TA"], j["TB"]) == (lay.TA, lay.TB)
+    j.update(L.pack_job_fields(lay))
+    out = torch.empty(lay.bytes, dtype=torch.uint8, device="cuda")
     j.update(src=w.data_ptr(), dst=out.data_ptr(), Cout=Cout, Cin=Cin, KH=k, KW=k)
-    _run_jobs([j], L.PackJob, L.lib.mfc_pack_weights, L.BF16 if dtype == torch.bfloat16 else L.F32)
+    _run_jobs([j], L.PackJob, L.lib.mfc_pack_weights, desc.dtype)
     return out
 
 
@@ -87,12 +90,13 @@ def conv2d(x, w, k, stride=1, bias=None, in_coef=None, in_relu=False, ipg=None, 
     Cout, Cin = w.shape[0], w.shape[1]
     pad = k // 2
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    wp = pack_weight(w, x.dtype, "fwd")
     out = torch.zeros(N, Ho, Wo, rup(Cout, 8), dtype=x.dtype, device="cuda")
-    d = L.ConvDesc(x.data_ptr(), wp.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else 0,
+    d = L.ConvDesc(x.data_ptr(), 0, out.data_ptr(), bias.data_ptr() if bias is not None else 0,
                    in_coef.data_ptr() if in_coef is not None else 0, stats.data_ptr() if stats is not None else 0,
                    dt_of(x), N, H, W, Cp, Cin, Ho, Wo, out.shape[3], Cout, Ho, Wo, k, k, -pad, -pad, stride, 1, 1, 0, 0,
                    1 if in_relu else 0, ipg or N, 0, tile[0], tile[1])
+    wp = pack_weight(w, d, "fwd")
+    d.wp = wp.data_ptr()
     L.call(L.lib.mfc_conv2d_fwd, d)
     return out
 
@@ -106,9 +110,10 @@ def conv2d_dgrad(dy, w, k, stride, in_hw, accumulate_into=None):
     dx = accumulate_into if accumulate_into is not None else torch.zeros(N, H, W, rup(Cin, 8), dtype=dy.dtype, device="cuda")
     acc = 1 if accumulate_into is not None else 0
     if stride == 1:
-        wp = pack_weight(w, dy.dtype, "dgrad")
-        d = L.ConvDesc(dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), 0, 0, 0, dt_of(dy), N, Ho, Wo, Cop, Cout, H, W, dx.shape[3],
+        d = L.ConvDesc(dy.data_ptr(), 0, dx.data_ptr(), 0, 0, 0, dt_of(dy), N, Ho, Wo, Cop, Cout, H, W, dx.shape[3],
                        Cin, H, W, k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, N, acc, 0, 0)
+        wp = pack_weight(w, d, "dgrad")
+        d.wp = wp.data_ptr()
         L.call(L.lib.mfc_conv2d_fwd, d)
     else:
         keep = []
@@ -116,11 +121,12 @@ def conv2d_dgrad(dy, w, k, stride, in_hw, accumulate_into=None):
             for pw in range(2):
                 ta, _, dh0 = s2_class(k, pad, ph)
                 tb, _, dw0 = s2_class(k, pad, pw)
-                wp = pack_weight(w, dy.dtype, "dgrad_s2", (ph, pw))
-                keep.append(wp)
                 Hl, Wl = (H - ph + 1) // 2, (W - pw + 1) // 2
-                d = L.ConvDesc(dy.data_ptr(), wp.data_ptr(), dx.data_ptr(), 0, 0, 0, dt_of(dy), N, Ho, Wo, Cop, Cout, H, W,
+                d = L.ConvDesc(dy.data_ptr(), 0, dx.data_ptr(), 0, 0, 0, dt_of(dy), N, Ho, Wo, Cop, Cout, H, W,
                                dx.shape[3], Cin, Hl, Wl, ta, tb, dh0, dw0, 1, 2, 2, ph, pw, 0, N, acc, 0, 0)
+                wp = pack_weight(w, d, "dgrad_s2", (ph, pw))
+                keep.append(wp)
+                d.wp = wp.data_ptr()
                 L.call(L.lib.mfc_conv2d_fwd, d)
         torch.cuda.synchronize()
     return dx

@@ -100,8 +100,7 @@ class ConvInfo:
     stride: int
     pad: int
     bias: Optional[str]
-    wp_fwd: int = 0
-    wp_dgrad: List[int] = field(default_factory=list)
+    dgrad: List = field(default_factory=list)     # data-gradient launch descriptors (1 for stride 1, 4 parity classes for stride 2)
     dwp: int = 0
 
 
@@ -166,32 +165,42 @@ class Plan:
         return L.View(t.ptr, bn.coef if bn else 0, t.H, t.W, t.Cp, c_off)
 
     # ------------------------------------------------------------------ conv bookkeeping
-    def conv_info(self, wname, cout, cin, k, stride, bias) -> ConvInfo:
-        E = self.E
+    def _pack(self, desc, src, cout, cin, k, **tap):
+        """allocate the packed image the launch `desc` reads, queue its pack job, point the descriptor at it"""
+        lay = L.conv_layout(desc)
+        assert (lay.TA, lay.TB) == (tap["TA"], tap["TB"])
+        dst = self._alloc("act", lay.bytes)
+        job = dict(src=src, dst=dst, Cout=cout, Cin=cin, KH=k, KW=k, **tap)
+        job.update(L.pack_job_fields(lay))
+        self.pack_jobs.append(job)
+        desc.wp = dst
+
+    def conv_info(self, fwd_desc, xt, y, wname, cout, cin, k, stride, bias) -> ConvInfo:
         ci = ConvInfo(wname, cout, cin, k, stride, k // 2, (wname[:-6] + "bias") if bias else None)
-        Kg, Np = -(-cin // E), rup(cout, 16)
-        ci.wp_fwd = self._alloc("act", k * k * Kg * Np * 16)
+        pad = ci.pad
         src = self.pptr(wname)
-        self.pack_jobs.append(dict(src=src, dst=ci.wp_fwd, Cout=cout, Cin=cin, KH=k, KW=k, TA=k, TB=k, kh0=0, kh_step=1,
-                                   kw0=0, kw_step=1, mode=0, Kg=Kg, Np=Np))
+        self._pack(fwd_desc, src, cout, cin, k, TA=k, TB=k, kh0=0, kh_step=1, kw0=0, kw_step=1, mode=0)
         if self.need_backward:
-            Kg2, Np2 = -(-cout // E), rup(cin, 16)
-            if stride == 1:
-                p = self._alloc("act", k * k * Kg2 * Np2 * 16)
-                ci.wp_dgrad = [p]
-                self.pack_jobs.append(dict(src=src, dst=p, Cout=cout, Cin=cin, KH=k, KW=k, TA=k, TB=k, kh0=k - 1,
-                                           kh_step=-1, kw0=k - 1, kw_step=-1, mode=1, Kg=Kg2, Np=Np2))
-            else:
-                assert stride == 2
-                ci.wp_dgrad = []
-                for ph in range(2):
-                    for pw in range(2):
-                        ta, kh0, _ = self._s2_class(k, ci.pad, ph)
-                        tb, kw0, _ = self._s2_class(k, ci.pad, pw)
-                        p = self._alloc("act", ta * tb * Kg2 * Np2 * 16)
-                        ci.wp_dgrad.append(p)
-                        self.pack_jobs.append(dict(src=src, dst=p, Cout=cout, Cin=cin, KH=k, KW=k, TA=ta, TB=tb, kh0=kh0,
-                                                   kh_step=-2, kw0=kw0, kw_step=-2, mode=1, Kg=Kg2, Np=Np2))
+            ci.dgrad = []
+            if xt.needs_grad:
+                if stride == 1:
+                    d = L.ConvDesc(16, 0, 16, 0, 0, 0, self.dtype, y.N, y.H, y.W, y.Cp, cout, xt.H, xt.W, xt.Cp, xt.C, xt.H, xt.W,
+                                   k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, y.ipg, 0, 0, 0)
+                    self._pack(d, src, cout, cin, k, TA=k, TB=k, kh0=k - 1, kh_step=-1, kw0=k - 1, kw_step=-1, mode=1)
+                    ci.dgrad.append(d)
+                else:
+                    assert stride == 2
+                    for ph in range(2):
+                        for pw in range(2):
+                            ta, kh0, dh0 = self._s2_class(k, pad, ph)
+                            tb, kw0, dw0 = self._s2_class(k, pad, pw)
+                            Hl, Wl = (xt.H - ph + 1) // 2, (xt.W - pw + 1) // 2
+                            if Hl <= 0 or Wl <= 0:
+                                continue
+                            d = L.ConvDesc(16, 0, 16, 0, 0, 0, self.dtype, y.N, y.H, y.W, y.Cp, cout, xt.H, xt.W, xt.Cp, xt.C, Hl, Wl,
+                                           ta, tb, dh0, dw0, 1, 2, 2, ph, pw, 0, y.ipg, 0, 0, 0)
+                            self._pack(d, src, cout, cin, k, TA=ta, TB=tb, kh0=kh0, kh_step=-2, kw0=kw0, kw_step=-2, mode=1)
+                            ci.dgrad.append(d)
             Co16, Ci16 = rup(cout, 16), rup(cin, 16)
             ci.dwp = self._alloc("dwp", k * k * Co16 * Ci16 * 4)
             self.unpack_jobs.append(dict(src=ci.dwp, dst=self.gptr(wname), Cout=cout, Cin=cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16))
@@ -210,12 +219,12 @@ class Plan:
         pad = k // 2
         Ho, Wo = (xt.H + 2 * pad - k) // stride + 1, (xt.W + 2 * pad - k) // stride + 1
         y = self.tensor(xt.N, Ho, Wo, cout, xt.ipg, wname)
-        ci = self.conv_info(wname, cout, xt.C, k, stride, bias)
         bn = self.new_bn(bn_name, y, training) if bn_name else None
-        d = L.ConvDesc(xt.ptr, ci.wp_fwd, y.ptr, self.pptr(ci.bias) if bias else 0, x.bn.coef if x.bn else 0,
+        d = L.ConvDesc(xt.ptr, 0, y.ptr, self.pptr(wname[:-6] + "bias") if bias else 0, x.bn.coef if x.bn else 0,
                        bn.stats if (bn and bn.training) else 0, self.dtype, xt.N, xt.H, xt.W, xt.Cp, xt.C,
                        Ho, Wo, y.Cp, cout, Ho, Wo, k, k, -pad, -pad, stride, 1, 1, 0, 0,
                        1 if x.relu else 0, xt.ipg, 0, 0, 0)
+        ci = self.conv_info(d, xt, y, wname, cout, xt.C, k, stride, bias)
         self.fwd.append((L.OP_CONV, d))
         self.ops.append(("conv", x, y, ci, bn))
         if bn:
@@ -474,22 +483,9 @@ class Plan:
                 if xt.needs_grad:
                     dx = self.grad_of(xt)
                     acc = 1 if xt.grad_init else 0
-                    if s == 1:
-                        self.bwd.append((L.OP_CONV, L.ConvDesc(dy.ptr, ci.wp_dgrad[0], dx.ptr, 0, 0, 0, self.dtype, y.N, y.H, y.W,
-                                                               y.Cp, ci.cout, xt.H, xt.W, xt.Cp, xt.C, xt.H, xt.W, k, k,
-                                                               -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, y.ipg, acc, 0, 0)))
-                    else:
-                        idx = 0
-                        for ph in range(2):
-                            for pw in range(2):
-                                ta, _, dh0 = self._s2_class(k, pad, ph)
-                                tb, _, dw0 = self._s2_class(k, pad, pw)
-                                Hl, Wl = (xt.H - ph + 1) // 2, (xt.W - pw + 1) // 2
-                                if Hl > 0 and Wl > 0:
-                                    self.bwd.append((L.OP_CONV, L.ConvDesc(dy.ptr, ci.wp_dgrad[idx], dx.ptr, 0, 0, 0, self.dtype, y.N, y.H,
-                                                                           y.W, y.Cp, ci.cout, xt.H, xt.W, xt.Cp, xt.C, Hl, Wl, ta, tb,
-                                                                           dh0, dw0, 1, 2, 2, ph, pw, 0, y.ipg, acc, 0, 0)))
-                                idx += 1
+                    for d in ci.dgrad:
+                        d.inp, d.out, d.accumulate = dy.ptr, dx.ptr, acc
+                        self.bwd.append((L.OP_CONV, d))
                     xt.grad_init = True
                     if x.bn is not None:
                         xt.virtual_consumed, xt.virtual_relu = True, x.relu
@@ -502,7 +498,7 @@ class Plan:
             for k_, v in j.items():
                 setattr(arr[i], k_, v)
             if cls is L.PackJob:
-                total = j["TA"] * j["TB"] * j["Kg"] * j["Np"]
+                total = j["TA"] * j["nchunks"] * j["Yblocks"] * j["nslots"] * j["NT16"]
             else:
                 total = j["Cout"] * j["Cin"] * j["KH"] * j["KW"]
             nb = -(-total // per_block)
