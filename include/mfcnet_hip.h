@@ -89,10 +89,11 @@ typedef struct {
     int32_t TH, TW;                        /* pixel tile (TH*TW <= 128); 0 = choose */
 } mfc_conv_desc;
 int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream);
-/* The packed weight image a launch of `d` reads is laid out [TA][nchunks][Yblocks][nslots][NT16][granule]: the
- * weights of one (tap row, channel chunk, cout block) stage are one contiguous block that is DMA-copied
+/* The packed weight image a launch of `d` reads is laid out [TA/TAS][nchunks][Yblocks][nslots][NT16][granule]
+ * (slot = (row-in-group, tap column, granule-in-chunk)): the weights of one (tap-row group, channel chunk, cout block) stage are one contiguous block that is DMA-copied
  * straight into LDS.  The blocking depends on the launch geometry, so the packer asks for it here.      */
-typedef struct { int32_t KG, nchunks, NT16, Yblocks, nslots, TA, TB, lds_bytes; int64_t bytes; } mfc_conv_layout;
+typedef struct { int32_t KG, nchunks, NT16, Yblocks, nslots, TA, TB, lds_bytes; int64_t bytes;
+                 int32_t MT, TH, TW, grid, per_block, TAS; } mfc_conv_layout;   /* last row: launch geometry (informational) */
 int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
 /* LDS bytes a launch of `d` needs (for tests / planners); <0 on invalid desc. */
 int mfc_conv2d_lds_bytes(const mfc_conv_desc* d);
@@ -110,9 +111,10 @@ typedef struct {
     int32_t Cout, Cin, KH, KW;
     int32_t TA, TB, kh0, kh_step, kw0, kw_step;
     int32_t mode;            /* 0 fwd, 1 dgrad */
-    int32_t KG, nchunks, NT16, Yblocks, nslots;
+    int32_t KG, nchunks, NT16, Yblocks, nslots, TAS;
     int32_t block0;          /* first block of this job in the launch (prefix sum) */
     int32_t nblocks;
+    int32_t pad_;
 } mfc_pack_job;
 int mfc_pack_weights(const mfc_pack_job* jobs_dev, int32_t njobs, int32_t total_blocks, int32_t dtype, void* stream);
 

@@ -31,7 +31,7 @@ struct ConvK {
     int osh, osw, ooh, oow;
     int in_relu, ipg, G, accumulate;
     int TH, TW, tilesY, tilesX, ntiles;
-    int KG, nchunks;                    // chunk granules (Cin_g % KG == 0), #chunks
+    int KG, nchunks, TAS, nstg;         // chunk granules (Cin_g % KG == 0), #chunks, tap rows per stage, stages per chunk
     int PH, PW, pitch;                  // patch dims (pixels) and pixel pitch (bytes)
     int Yblocks, nunits, per_block;     // units = cout blocks (slow) x tiles (fast); units per workgroup
     int nslots, npieces, stage_bytes;   // weight slots per stage, 1-KiB DMA pieces per stage, bytes of one stage image
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     const int u0 = Lb * p.per_block;
     const int nun = min(p.per_block, p.nunits - u0);
     if (nun <= 0) return;
-    const int SPT = p.nchunks * p.TA;
+    const int SPT = p.nchunks * p.nstg;
     const int total = nun * SPT;
     const int npix = p.PH * p.PW;
     const int cq = (lane >> 4) * 4;
@@ -92,9 +92,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     }
     // slot -> patch offset table (tail slots repeat the last valid one; their packed weights are zero)
     if (tid < p.nslots) {
-        int q = min(tid, p.TB * kg - 1);
+        int q = min(tid, p.TAS * p.TB * kg - 1);
+        int al = q / (p.TB * kg); q -= al * p.TB * kg;
         int b = q / kg, gi = q - b * kg;
-        ktab[tid] = b * p.pitch + gi * 16;
+        ktab[tid] = (al * p.PW + b) * p.pitch + gi * 16;
     }
 
     f32x4 acc[MT][NT];
@@ -111,14 +112,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     float sc[E], sh[E];
     const bool p_xf = (p.in_coef != nullptr);
 
-    auto unit_coords = [&](int u, int& n, int& i0, int& j0, int& yb) {     // cout block slowest, tiles fastest
-        yb = u / p.ntiles; int xt = u - yb * p.ntiles;
-        const int txi = xt % p.tilesX; xt /= p.tilesX;
-        const int tyi = xt % p.tilesY; n = xt / p.tilesY;
-        i0 = tyi * p.TH; j0 = txi * p.TW;
+    // unit = (cout block yb [slowest], image n, tile row, tile column [fastest]); tracked incrementally (no divisions per stage)
+    struct UC { int yb, n, tyi, txi; };
+    auto uc_init = [&](int u) {
+        UC r; r.yb = u / p.ntiles; int xt = u - r.yb * p.ntiles;
+        r.txi = xt % p.tilesX; xt /= p.tilesX; r.tyi = xt % p.tilesY; r.n = xt / p.tilesY;
+        return r;
     };
-    auto load_patch = [&](int u, int c) {
-        int n, i0, j0, yb; unit_coords(u, n, i0, j0, yb);
+    auto uc_next = [&](UC r) {
+        if (++r.txi == p.tilesX) { r.txi = 0; if (++r.tyi == p.tilesY) { r.tyi = 0; if (++r.n == p.N) { r.n = 0; ++r.yb; } } }
+        return r;
+    };
+    auto load_patch = [&](const UC& uc, int c) {
+        const int n = uc.n, i0 = uc.tyi * p.TH, j0 = uc.txi * p.TW;
         const int g0 = c * kg;
         pmask = 0;
         if (p_gi < kg) {
@@ -165,9 +171,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     };
     // async global -> LDS copy of the packed weights of stage (a, c, cout block): the packed image is laid out
     // [TA][nchunks][Yblocks][nslots][NT16][16 B], i.e. one stage is ONE contiguous block = the LDS image
-    auto dma_w = [&](int u, int c, int a, char* wl) {
-        const int yb = u / p.ntiles;
-        const char* src = p.wp + (size_t)((a * p.nchunks + c) * p.Yblocks + yb) * p.stage_bytes + lane * 16;
+    auto dma_w = [&](const UC& uc, int c, int ag, char* wl) {
+        const char* src = p.wp + (size_t)((ag * p.nchunks + c) * p.Yblocks + uc.yb) * p.stage_bytes + lane * 16;
         for (int piece = wave; piece < p.npieces; piece += 4)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + piece * 1024), (lds_void_t*)(wl + piece * 1024), 16, 0, 0);
     };
@@ -201,26 +206,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     };
 
     // ---------------- prologue ----------------
-    dma_w(u0, 0, 0, smem + p.off_w0);
-    load_patch(u0, 0);
+    UC uc = uc_init(u0), uc2 = uc;
+    dma_w(uc, 0, 0, smem + p.off_w0);
+    load_patch(uc, 0);
     store_patch();
     __syncthreads();
 
-    int tl = 0, c = 0, a = 0;          // current stage coordinates
+    int tl = 0, c = 0, a = 0;          // current stage coordinates (a = tap-row group)
     for (int g = 0; g < total; ++g) {
-        const int u = u0 + tl;
         int tl2 = tl, c2 = c, a2 = a + 1;
-        if (a2 == p.TA) { a2 = 0; ++c2; if (c2 == p.nchunks) { c2 = 0; ++tl2; } }
+        if (a2 == p.nstg) { a2 = 0; ++c2; if (c2 == p.nchunks) { c2 = 0; ++tl2; uc2 = uc_next(uc); } }
         const bool nxt = (g + 1 < total);
         const bool newpatch = nxt && (a2 == 0) && (p.nchunks > 1 || tl2 != tl);
-        if (nxt) dma_w(u0 + tl2, c2, a2, smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
-        if (newpatch) load_patch(u0 + tl2, c2);
+        if (nxt) dma_w(uc2, c2, a2, smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
+        if (newpatch) load_patch(uc2, c2);
         if (red_pending) stats_flush();
 
         // ---------------- compute stage (tl, c, a) ----------------
         {
             const char* wl = smem + ((g & 1) ? p.off_w1 : p.off_w0);
-            const char* pa = patch + a * p.PW * p.pitch;
+            const char* pa = patch + a * p.TAS * p.PW * p.pitch;
             if constexpr (BF) {
                 const int nk = p.nslots >> 2;
                 const int gl = lane >> 4;
@@ -257,8 +262,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         }
 
         // ---------------- tile epilogue ----------------
-        if (c == p.nchunks - 1 && a == p.TA - 1) {
-            int n, i0, j0, yb; unit_coords(u, n, i0, j0, yb);
+        if (c == p.nchunks - 1 && a == p.nstg - 1) {
+            const int n = uc.n, i0 = uc.tyi * p.TH, j0 = uc.txi * p.TW, yb = uc.yb;
             const int n0 = yb * NT16;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -300,10 +305,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                 // flush the running sums when the next unit belongs to another (statistic group, cout block) or the run ends
                 bool flush = (tl + 1 >= nun);
                 if (!flush) {
-                    int n2, i2, j2, yb2; unit_coords(u + 1, n2, i2, j2, yb2);
-                    flush = (yb2 != yb) || (n2 / p.ipg != n / p.ipg);
+                    const UC un = uc_next(uc);
+                    flush = (un.yb != yb) || (un.n / p.ipg != n / p.ipg);
                 }
-                if (flush) stats_to_lds(n0, n / p.ipg, (u + blockIdx.x) % MFC_R);
+                if (flush) stats_to_lds(n0, n / p.ipg, (u0 + tl + blockIdx.x) % MFC_R);
             }
         }
 
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             store_patch();
         }
         __syncthreads();               // (drains the weight DMA of stage g+1: vmcnt(0) precedes the barrier)
-        tl = tl2; c = c2; a = a2;
+        tl = tl2; c = c2; a = a2; uc = uc2;
     }
     if (red_pending) stats_flush();
 }
@@ -334,6 +339,8 @@ static void choose_tile(int Hl, int Wl, int cap, int& TH, int& TW, double& eff_o
 }
 
 static int g_conv_num_cu = 256;
+static int g_conv_force_mt = 0;      // tuning: mfc_set_flag(2, 2|4)
+int mfc_conv_set_force_mt(int v) { g_conv_force_mt = v; return 0; }
 
 static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid) {
     if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
@@ -360,53 +367,58 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
         }
     }
     k.Yblocks = ceil_div(n16, NT);
-    // pixel tile: 256 pixels (4 m-tiles per wave: fewer LDS reads per MFMA) unless 128 covers the image better
-    // or the halo patch / prefetch registers do not fit
-    int cand_mt[2] = {4, 2};
-    bool ok = false;
-    for (int ci = 0; ci < 2 && !ok; ++ci) {
-        MT = cand_mt[ci];
-        const int cap = 64 * MT;
+    // Search the launch geometry: pixel tile (256 or 128 pixels), tap rows per stage (all or one) and channel chunk KG,
+    // subject to LDS <= 80 KiB (2 workgroups per CU) and the per-thread patch-piece budget; prefer the most MFMAs per
+    // stage (fewer barriers / less per-stage bookkeeping per MFMA), discounted by padding waste.
+    double best_score = -1; ConvK bk = k; int bMT = 2, bPM = 0; size_t blds = 0;
+    for (int mi = 0; mi < 2; ++mi) {
+        const int mt = mi == 0 ? 4 : 2;
+        if (g_conv_force_mt && mt != g_conv_force_mt) continue;
+        const int cap = 64 * mt;
+        ConvK c = k; double eff;
         if (d->TH > 0 && d->TW > 0) {
-            if (d->TH * d->TW > cap) continue;
-            if (MT == 4 && d->TH * d->TW <= 128) continue;
-            k.TH = d->TH; k.TW = d->TW;
+            if (d->TH * d->TW > cap || (mt == 4 && d->TH * d->TW <= 128)) continue;
+            c.TH = d->TH; c.TW = d->TW;
+            eff = (double)d->Hl * d->Wl / ((double)ceil_div(d->Hl, c.TH) * ceil_div(d->Wl, c.TW) * cap);
         } else {
-            double e4, e2; int th2, tw2;
-            choose_tile(d->Hl, d->Wl, cap, k.TH, k.TW, e4);
-            if (MT == 4) {
-                choose_tile(d->Hl, d->Wl, 128, th2, tw2, e2);
-                if (e2 > e4 * 1.08) continue;            // the smaller tile wastes clearly fewer MFMA rows
-                if (d->in_stride > 1) continue;          // strided patches are 4x larger: keep the 128-pixel tile
+            choose_tile(d->Hl, d->Wl, cap, c.TH, c.TW, eff);
+        }
+        c.tilesY = ceil_div(d->Hl, c.TH); c.tilesX = ceil_div(d->Wl, c.TW);
+        c.PH = (c.TH - 1) * c.s + c.TA; c.PW = (c.TW - 1) * c.s + c.TB;
+        const long units = (long)c.N * c.tilesY * c.tilesX * c.Yblocks;
+        // parallelism: a launch wants >= ~2 units per CU-slot (512 slots); fewer units -> idle CUs
+        const double fill = units >= 512 ? 1.0 : (double)units / 512.0;
+        for (int tas = c.TA; tas >= 1; tas = (tas == 1 ? 0 : 1)) {
+            const int kgcap = (c.TB * tas == 1) ? 16 : 8;
+            for (int kg = (c.Cin_g < kgcap ? c.Cin_g : kgcap); kg >= 1; --kg) {
+                if (c.Cin_g % kg) continue;
+                ConvK t = c;
+                t.KG = kg; t.nchunks = t.Cin_g / kg; t.TAS = tas; t.nstg = t.TA / tas;
+                int P = kg; while (P % 4 != 2) ++P;      // pixel pitch in 16-B slots: conflict-free ds_read_b128 fragments
+                if (E == 4) P = kg + 1;
+                t.pitch = P * 16;
+                const int real = tas * t.TB * kg;
+                t.nslots = (E == 8) ? ((real + 3) & ~3) : real;
+                int KGP = 1; while (KGP < kg) KGP <<= 1;
+                const size_t patch = (size_t)t.PH * t.PW * t.pitch;
+                t.stage_bytes = t.nslots * NT * 16 * 16;
+                const size_t wbytes = ((size_t)t.stage_bytes + 1023) & ~(size_t)1023;
+                t.npieces = (int)(wbytes / 1024);
+                t.off_w0 = (int)((patch + 1023) & ~(size_t)1023);
+                t.off_w1 = t.off_w0 + (int)wbytes;
+                t.off_ktab = t.off_w1 + (int)wbytes;
+                t.off_red = t.off_ktab + ((t.nslots * 4 + 15) & ~15);
+                const size_t l = (size_t)t.off_red + (size_t)2 * 4 * 2 * NT * 16 * 4;
+                const int pm = ceil_div(t.PH * t.PW, 256 / KGP);
+                if (l > 80 * 1024 || pm > (mt == 4 ? 6 : 10) || t.nslots > 256) continue;
+                const double mf = (E == 8 ? t.nslots / 4 : t.nslots) * mt * NT;      // MFMAs per wave per stage
+                const double score = eff * fill * ((double)real / t.nslots) * (mf / (mf + 40.0)) * (mt == 4 ? 1.0 : 0.93);
+                if (score > best_score) { best_score = score; bk = t; bMT = mt; bPM = pm; blds = l; }
             }
         }
-        k.tilesY = ceil_div(d->Hl, k.TH); k.tilesX = ceil_div(d->Wl, k.TW);
-        k.PH = (k.TH - 1) * k.s + k.TA; k.PW = (k.TW - 1) * k.s + k.TB;
-        // channel chunk: the largest divisor of Cin_g (<= 8 granules) whose LDS image fits 64 KiB (-> 2 workgroups/CU)
-        // and whose staging fits the per-thread piece budgets
-        for (int kg = (k.Cin_g < 8 ? k.Cin_g : 8); kg >= 1; --kg) {
-            if (k.Cin_g % kg) continue;
-            k.KG = kg; k.nchunks = k.Cin_g / kg;
-            // pixel pitch in 16-B slots: smallest P >= kg with P % 4 == 2 -> conflict-free ds_read_b128 fragment reads
-            int P = kg; while (P % 4 != 2) ++P;
-            if (E == 4) P = kg + 1;
-            k.pitch = P * 16;
-            k.nslots = (E == 8) ? ((k.TB * kg + 3) & ~3) : k.TB * kg;
-            int KGP = 1; while (KGP < kg) KGP <<= 1;
-            const size_t patch = (size_t)k.PH * k.PW * k.pitch;
-            const size_t wbytes = ((size_t)k.nslots * NT * 16 * 16 + 1023) & ~(size_t)1023;
-            k.npieces = (int)(wbytes / 1024);
-            k.stage_bytes = k.nslots * NT * 16 * 16;
-            k.off_w0 = (int)((patch + 1023) & ~(size_t)1023);
-            k.off_w1 = k.off_w0 + (int)wbytes;
-            k.off_ktab = k.off_w1 + (int)wbytes;
-            k.off_red = k.off_ktab + ((k.nslots * 4 + 15) & ~15);
-            lds = (size_t)k.off_red + (size_t)2 * 4 * 2 * NT * 16 * 4;
-            PM = ceil_div(k.PH * k.PW, 256 / KGP);
-            const bool regs_ok = PM <= (MT == 4 ? 6 : 10) && k.nslots <= 256;
-            if (lds <= 64 * 1024 && regs_ok) { ok = true; break; }
-        }
     }
+    const bool ok = best_score > 0;
+    k = bk; MT = bMT; PM = bPM; lds = blds;
     if (!ok) return MFC_ERR_UNSUPPORTED;
     k.ntiles = k.N * k.tilesY * k.tilesX;
     k.nunits = k.ntiles * k.Yblocks;
@@ -446,8 +458,9 @@ extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
     int rc = conv_setup(&t, k, NT, MT, PM, lds, grid);
     if (rc < 0 || !out) return rc < 0 ? rc : MFC_ERR_INVALID_ARG;
     out->KG = k.KG; out->nchunks = k.nchunks; out->NT16 = NT * 16; out->Yblocks = k.Yblocks; out->nslots = k.nslots;
-    out->TA = k.TA; out->TB = k.TB; out->lds_bytes = (int32_t)lds;
-    out->bytes = (int64_t)k.TA * k.nchunks * k.Yblocks * k.stage_bytes;
+    out->TA = k.TA; out->TB = k.TB; out->lds_bytes = (int32_t)lds; out->TAS = k.TAS;
+    out->bytes = (int64_t)k.nstg * k.nchunks * k.Yblocks * k.stage_bytes;
+    out->MT = MT; out->TH = k.TH; out->TW = k.TW; out->grid = grid; out->per_block = k.per_block;
     return MFC_OK;
 }
 

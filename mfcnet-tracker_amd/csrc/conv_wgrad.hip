@@ -13,8 +13,10 @@
 #include "common.h"
 
 static int g_wgrad_use_tr = 1;
+int mfc_conv_set_force_mt(int v);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
+    if (id == 2) return mfc_conv_set_force_mt(value);
     return MFC_ERR_INVALID_ARG;
 }
 

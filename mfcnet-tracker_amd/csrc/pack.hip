@@ -17,16 +17,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const mfc_pack_job* jobs, int njobs) {
     constexpr int E = Gran<T>::E;
     const mfc_pack_job j = jobs[find_job(jobs, njobs, blockIdx.x)];
-    const long total = (long)j.TA * j.nchunks * j.Yblocks * j.nslots * j.NT16;
+    const long total = (long)(j.TA / j.TAS) * j.nchunks * j.Yblocks * j.nslots * j.NT16;
     long idx = (long)(blockIdx.x - j.block0) * 256 + threadIdx.x;
     if (idx >= total) return;
     const int nn = (int)(idx % j.NT16); long r = idx / j.NT16;
     const int slot = (int)(r % j.nslots); r /= j.nslots;
     const int yb = (int)(r % j.Yblocks); r /= j.Yblocks;
-    const int c = (int)(r % j.nchunks); const int a = (int)(r / j.nchunks);
-    const int b = slot / j.KG, gi = slot - b * j.KG;
-    const bool sv = slot < j.TB * j.KG;
-    const int kh = j.kh0 + a * j.kh_step, kw = j.kw0 + b * j.kw_step;
+    const int c = (int)(r % j.nchunks); const int ag = (int)(r / j.nchunks);
+    const bool sv = slot < j.TAS * j.TB * j.KG;
+    const int al = slot / (j.TB * j.KG); const int rs = slot - al * j.TB * j.KG;
+    const int b = rs / j.KG, gi = rs - b * j.KG;
+    const int kh = j.kh0 + (ag * j.TAS + al) * j.kh_step, kw = j.kw0 + b * j.kw_step;
     const int n = yb * j.NT16 + nn;
     const float* src = (const float*)j.src;
     float f[E];

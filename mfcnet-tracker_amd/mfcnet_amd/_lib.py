@@ -39,12 +39,13 @@ class PackJob(C.Structure):
     _fields_ = [("src", u64), ("dst", u64), ("Cout", i32), ("Cin", i32), ("KH", i32), ("KW", i32),
                 ("TA", i32), ("TB", i32), ("kh0", i32), ("kh_step", i32), ("kw0", i32), ("kw_step", i32),
                 ("mode", i32), ("KG", i32), ("nchunks", i32), ("NT16", i32), ("Yblocks", i32), ("nslots", i32),
-                ("block0", i32), ("nblocks", i32)]
+                ("TAS", i32), ("block0", i32), ("nblocks", i32), ("pad_", i32)]
 
 
 class ConvLayout(C.Structure):
     _fields_ = [("KG", i32), ("nchunks", i32), ("NT16", i32), ("Yblocks", i32), ("nslots", i32), ("TA", i32), ("TB", i32),
-                ("lds_bytes", i32), ("bytes", C.c_int64)]
+                ("lds_bytes", i32), ("bytes", C.c_int64), ("MT", i32), ("TH", i32), ("TW", i32), ("grid", i32),
+                ("per_block", i32), ("TAS", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -193,4 +194,4 @@ def conv_layout(desc: ConvDesc) -> ConvLayout:
 
 
 def pack_job_fields(lay: ConvLayout) -> dict:
-    return dict(KG=lay.KG, nchunks=lay.nchunks, NT16=lay.NT16, Yblocks=lay.Yblocks, nslots=lay.nslots)
+    return dict(KG=lay.KG, nchunks=lay.nchunks, NT16=lay.NT16, Yblocks=lay.Yblocks, nslots=lay.nslots, TAS=lay.TAS)

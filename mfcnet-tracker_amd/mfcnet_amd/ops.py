@@ -47,7 +47,7 @@ def _run_jobs(jobs, cls, fn, *extra):
     for i, j in enumerate(jobs):
         for k, v in j.items():
             setattr(arr[i], k, v)
-        total = (j["TA"] * j["nchunks"] * j["Yblocks"] * j["nslots"] * j["NT16"] if cls is L.PackJob
+        total = ((j["TA"] // j["TAS"]) * j["nchunks"] * j["Yblocks"] * j["nslots"] * j["NT16"] if cls is L.PackJob
                  else j["Cout"] * j["Cin"] * j["KH"] * j["KW"])
         arr[i].block0, arr[i].nblocks = b0, -(-total // 256)
         b0 += arr[i].nblocks

@@ -498,7 +498,7 @@ class Plan:
             for k_, v in j.items():
                 setattr(arr[i], k_, v)
             if cls is L.PackJob:
-                total = j["TA"] * j["nchunks"] * j["Yblocks"] * j["nslots"] * j["NT16"]
+                total = (j["TA"] // j["TAS"]) * j["nchunks"] * j["Yblocks"] * j["nslots"] * j["NT16"]
             else:
                 total = j["Cout"] * j["Cin"] * j["KH"] * j["KW"]
             nb = -(-total // per_block)

@@ -25,6 +25,8 @@ def timeit(fn, iters=20):
 def main():
     dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
     what = sys.argv[2] if len(sys.argv) > 2 else "both"
+    if len(sys.argv) > 3:
+        L.lib.mfc_set_flag(2, int(sys.argv[3]))
     for (N, Cin, Cout, k, s, H, W) in SHAPES:
         pad = k // 2
         Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
@@ -43,6 +45,9 @@ def main():
                 if st is not None and N % 3:
                     continue
                 wp = ops.pack_weight(w, d, "fwd"); d.wp = wp.data_ptr()
+                if label == "plain":
+                    lay = L.conv_layout(d)
+                    line += f" [NT{lay.NT16//16} MT{lay.MT} {lay.TH}x{lay.TW} KG{lay.KG} TAS{lay.TAS} lds{lay.lds_bytes//1024}K g{lay.grid}x{lay.per_block}]"
                 t = timeit(lambda: L.call(L.lib.mfc_conv2d_fwd, d))
                 line += f" | fwd-{label} {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF"
         if what in ("wgrad", "both"):
