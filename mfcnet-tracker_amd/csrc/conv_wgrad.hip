@@ -205,6 +205,226 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
     }
 }
 
+// ================================================================================================
+// Fast bf16 path: register-tiled, double-buffered, prefetched.
+//   * a wave owns a TB x WCO x WCI block of 16x16 accumulator tiles: per 32-pixel k-step it reads WCO
+//     dy^T fragments once (shared by all taps) and TB*WCI input fragments -> ~0.9 transpose reads / MFMA;
+//   * the 4 waves of a workgroup are arranged gc x gi x gk: gc*WCO cout tiles, gi*WCI cin tiles, and gk-way
+//     split of the pixel (K) axis (small channel counts: every wave holds ALL tiles and takes every gk-th
+//     k-step; partial sums meet in the final atomics);
+//   * the dy tile and the input rows of the NEXT pixel tile are prefetched into registers while the MFMAs
+//     of the current one run from the other LDS buffer: one barrier per pixel tile.
+// ================================================================================================
+#define WG_DP 6     // max dy pieces (16 B) a thread prefetches per pixel tile
+#define WG_XP 7     // max input pieces
+
+struct WgradF {
+    const char* x; const char* dy; float* dwp; const float* in_coef;
+    int N, Hin, Win, Cin_p, Hout, Wout, Cout_p;
+    int TA, TB, dh0, dw0, s, in_relu, ipg;
+    int TH, TW, tilesY, tilesX, ntiles, splits;
+    int Co16, Ci16, co_blocks, ci_blocks;
+    int gc, gi, gk;                   // wave arrangement
+    int gd, gx;                       // granules per pixel staged for dy / x
+    int PW, pitch_d, pitch_x, buf_bytes, off_x, off_tab, off_coef, G;
+};
+
+template <int TB, int WCO, int WCI>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(WgradF p) {
+    typedef bf16_t T;
+    constexpr int E = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* xoff = (int*)(smem + p.off_tab);        // [128] patch byte offset of pixel (tap b = 0), 0 for padded pixels
+    float* coefs = (float*)(smem + p.off_coef);  // [G][2][gx*8] scale / shift of this block's input channels
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int y = blockIdx.y;
+    const int ib = y % p.ci_blocks; y /= p.ci_blocks;
+    const int cb = y % p.co_blocks; const int a = y / p.co_blocks;
+    const int wc = wave % p.gc, wi = (wave / p.gc) % p.gi, wk = wave / (p.gc * p.gi);
+    const int co0 = cb * p.gc * WCO * 16, ci0 = ib * p.gi * WCI * 16;      // block origin (channels)
+    const int cow = wc * WCO * 16, ciw = wi * WCI * 16;                    // wave origin inside the block
+
+    if (tid < 128) {
+        int ty = tid / p.TW, tx = tid - ty * p.TW;
+        xoff[tid] = (tid < p.TH * p.TW) ? (ty * p.PW + tx * p.s) * p.pitch_x : 0;
+    }
+    if (p.in_coef) {
+        const int nch = p.gx * 8;
+        for (int i = tid; i < p.G * 2 * nch; i += 256) {
+            const int ch = i % nch, w = (i / nch) & 1, g = i / (2 * nch);
+            coefs[i] = (ci0 + ch < p.Cin_p) ? p.in_coef[((size_t)g * 4 + w) * p.Cin_p + ci0 + ch] : 0.f;
+        }
+    }
+    // staging tables: dy piece i covers pixel tid/GDP + i*dstep, granule d_gi; x piece i covers patch pixel tid/GXP + i*xstep
+    int GDP = 1; while (GDP < p.gd) GDP <<= 1;
+    int GXP = 1; while (GXP < p.gx) GXP <<= 1;
+    const int d_gi = tid & (GDP - 1), dstep = 256 / GDP;
+    const int x_gi = tid & (GXP - 1), xstep = 256 / GXP;
+    const bool d_ok = d_gi < p.gd && (co0 + d_gi * E) < p.Cout_p;
+    const bool x_ok = x_gi < p.gx && (ci0 + x_gi * E) < p.Cin_p;
+    const int npx = p.TH * p.PW;
+    int dpyx[WG_DP], xpyx[WG_XP];
+#pragma unroll
+    for (int i = 0; i < WG_DP; ++i) {
+        const int pp = tid / GDP + i * dstep;
+        const int ty = pp / p.TW, tx = pp - ty * p.TW;
+        dpyx[i] = (pp < 128 && d_gi < p.gd) ? ((pp < p.TH * p.TW) ? ((ty << 16) | tx) : (1 << 30)) : -1;   // 1<<30: zero row
+    }
+#pragma unroll
+    for (int i = 0; i < WG_XP; ++i) {
+        const int pix = tid / GXP + i * xstep;
+        const int ty = pix / p.PW, px = pix - ty * p.PW;
+        xpyx[i] = (pix < npx && x_gi < p.gx) ? ((ty << 16) | px) : -1;
+    }
+
+    f32x4 acc[TB][WCO][WCI];
+#pragma unroll
+    for (int b = 0; b < TB; ++b)
+#pragma unroll
+        for (int i = 0; i < WCO; ++i)
+#pragma unroll
+            for (int j = 0; j < WCI; ++j) acc[b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 dreg[WG_DP], xreg[WG_XP]; unsigned dmask = 0, xmask = 0;
+    int x_grp = 0;
+    const bool xf = (p.in_coef != nullptr) && x_ok;
+
+    auto tile_coords = [&](int tile, int& n, int& i0, int& j0) {
+        const int txi = tile % p.tilesX; int r = tile / p.tilesX;
+        const int tyi = r % p.tilesY; n = r / p.tilesY;
+        i0 = tyi * p.TH; j0 = txi * p.TW;
+    };
+    auto load_tile = [&](int tile) {
+        int n, i0, j0; tile_coords(tile, n, i0, j0);
+        dmask = 0; xmask = 0;
+        if (d_ok) {
+            const char* base = p.dy + ((size_t)n * p.Hout * p.Wout * p.Cout_p + co0) * sizeof(T) + (size_t)d_gi * 16;
+#pragma unroll
+            for (int i = 0; i < WG_DP; ++i) {
+                if (dpyx[i] >= 0 && dpyx[i] < (1 << 30)) {
+                    const int oi = i0 + (dpyx[i] >> 16), oj = j0 + (dpyx[i] & 0xffff);
+                    if (oi < p.Hout && oj < p.Wout) {
+                        dreg[i] = *(const uint4*)(base + (size_t)(oi * p.Wout + oj) * (p.Cout_p * (int)sizeof(T)));
+                        dmask |= 1u << i;
+                    }
+                }
+            }
+        }
+        x_grp = n / p.ipg;
+        if (x_ok) {
+            const char* base = p.x + ((size_t)n * p.Hin * p.Win * p.Cin_p + ci0) * sizeof(T) + (size_t)x_gi * 16;
+            const int ihb = i0 * p.s + p.dh0 + a, iwb = j0 * p.s + p.dw0;
+#pragma unroll
+            for (int i = 0; i < WG_XP; ++i) {
+                if (xpyx[i] >= 0) {
+                    const int ih = ihb + (xpyx[i] >> 16) * p.s, iw = iwb + (xpyx[i] & 0xffff);
+                    if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
+                        xreg[i] = *(const uint4*)(base + (size_t)(ih * p.Win + iw) * (p.Cin_p * (int)sizeof(T)));
+                        xmask |= 1u << i;
+                    }
+                }
+            }
+        }
+    };
+    auto store_tile = [&](char* buf) {
+        char* Ds = buf; char* Xs = buf + p.off_x;
+#pragma unroll
+        for (int i = 0; i < WG_DP; ++i) {
+            if (dpyx[i] >= 0) {
+                const int pp = tid / GDP + i * dstep;
+                *(uint4*)(Ds + pp * p.pitch_d + d_gi * 16) = (dmask & (1u << i)) ? dreg[i] : make_uint4(0, 0, 0, 0);
+            }
+        }
+        float sc[E], sh[E];
+        if (xf) {
+            const float* cf = coefs + (size_t)x_grp * 2 * (p.gx * 8) + x_gi * E;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { sc[e] = cf[e]; sh[e] = cf[p.gx * 8 + e]; }
+        }
+#pragma unroll
+        for (int i = 0; i < WG_XP; ++i) {
+            if (xpyx[i] >= 0) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (xmask & (1u << i)) {
+                    v = xreg[i];
+                    if (xf) {
+                        float f[E];
+                        Gran<T>::unpack(v, f);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            float t = f[e] * sc[e] + sh[e];
+                            f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
+                        }
+                        v = Gran<T>::pack(f);
+                    }
+                }
+                *(uint4*)(Xs + ((xpyx[i] >> 16) * p.PW + (xpyx[i] & 0xffff)) * p.pitch_x + x_gi * 16) = v;
+            }
+        }
+    };
+
+    typedef __attribute__((address_space(3))) s16x4 lds_s4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    int it = 0;
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) { load_tile(tile); store_tile(smem); }
+    __syncthreads();
+    for (; tile < p.ntiles; tile += p.splits, ++it) {
+        const int nxt = tile + p.splits;
+        if (nxt < p.ntiles) load_tile(nxt);
+        const char* Ds = smem + (it & 1) * p.buf_bytes;
+        const char* Xs = Ds + p.off_x;
+        const int csub = (lane & 3) * 8;
+#pragma unroll 1
+        for (int ks = wk; ks < 4; ks += p.gk) {
+            const int pr0 = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2);
+            const char* dA0 = Ds + pr0 * p.pitch_d + cow * 2 + csub;
+            const char* dA1 = dA0 + 4 * p.pitch_d;
+            const char* dB0 = Xs + xoff[pr0] + ciw * 2 + csub;
+            const char* dB1 = Xs + xoff[pr0 + 4] + ciw * 2 + csub;
+            bf16x8 af[WCO];
+#pragma unroll
+            for (int i = 0; i < WCO; ++i) {
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(dA0 + i * 32));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(dA1 + i * 32));
+                af[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                bf16x8 bfr[WCI];
+#pragma unroll
+                for (int j = 0; j < WCI; ++j) {
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(dB0 + b * p.pitch_x + j * 32));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(dB1 + b * p.pitch_x + j * 32));
+                    bfr[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                    for (int j = 0; j < WCI; ++j)
+                        acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[b][i][j], 0, 0, 0);
+            }
+        }
+        if (nxt < p.ntiles) store_tile(smem + ((it + 1) & 1) * p.buf_bytes);
+        __syncthreads();
+    }
+    // ---- flush: D[row = co][col = ci]; lane holds col = lane&15, rows 4*(lane>>4)+r ----
+#pragma unroll
+    for (int b = 0; b < TB; ++b)
+#pragma unroll
+        for (int i = 0; i < WCO; ++i)
+#pragma unroll
+            for (int j = 0; j < WCI; ++j) {
+                const int co = co0 + cow + i * 16 + (lane >> 4) * 4, ci = ci0 + ciw + j * 16 + (lane & 15);
+                if (co < p.Co16 && ci < p.Ci16) {
+                    float* o = p.dwp + ((size_t)(a * TB + b) * p.Co16 + co) * p.Ci16 + ci;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(o + (size_t)r * p.Ci16, acc[b][i][j][r]);
+                }
+            }
+}
+
 void mfc_choose_tile_wg(int Hl, int Wl, int& TH, int& TW) {
     double best = -1; int bh = 8, bw = 16;
     for (int tw = 1; tw <= 128 && tw <= Wl; ++tw) {
@@ -236,11 +456,83 @@ static int wgrad_launch(const WgradK& k, size_t lds, int Y, hipStream_t st) {
     return MFC_OK;
 }
 
+template <int TB, int WCO, int WCI>
+static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_fast_kernel<TB, WCO, WCI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (g_mfc_prof_on) {
+        const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB;
+        const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
+        mfc_prof_before(st, 1 * 16 + 8 + (TB == 1 ? 0 : TB == 3 ? 1 : 2), flops, bytes);
+    }
+    hipLaunchKernelGGL((conv_wgrad_fast_kernel<TB, WCO, WCI>), dim3(f.splits, Y), dim3(256), lds, st, f);
+    if (g_mfc_prof_on) mfc_prof_after(st);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// returns MFC_ERR_UNSUPPORTED when the geometry does not fit the fast kernel (caller falls back)
+static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st) {
+    if (d->dtype != MFC_BF16 || !g_wgrad_use_tr) return MFC_ERR_UNSUPPORTED;
+    if (d->TB != 1 && d->TB != 3 && d->TB != 11) return MFC_ERR_UNSUPPORTED;
+    WgradF f;
+    f.x = (const char*)d->x; f.dy = (const char*)d->dy; f.dwp = d->dwp; f.in_coef = d->in_coef;
+    f.N = d->N; f.Hin = d->Hin; f.Win = d->Win; f.Cin_p = d->Cin_p; f.Hout = d->Hout; f.Wout = d->Wout; f.Cout_p = d->Cout_p;
+    f.TA = d->TA; f.TB = d->TB; f.dh0 = d->dh0; f.dw0 = d->dw0; f.s = d->in_stride; f.in_relu = d->in_relu; f.ipg = d->images_per_group;
+    f.TH = d->TH; f.TW = d->TW;
+    if (f.TH <= 0 || f.TW <= 0) mfc_choose_tile_wg(d->Hout, d->Wout, f.TH, f.TW);
+    if (f.TH * f.TW > 128) return MFC_ERR_INVALID_ARG;
+    f.tilesY = ceil_div(d->Hout, f.TH); f.tilesX = ceil_div(d->Wout, f.TW);
+    f.ntiles = f.N * f.tilesY * f.tilesX;
+    f.Co16 = ceil_div(d->Cout, 16) * 16; f.Ci16 = ceil_div(d->Cin, 16) * 16;
+    const int co_t = f.Co16 / 16, ci_t = f.Ci16 / 16;
+    int WCO, WCI;
+    if (d->TB == 11) { WCO = 1; WCI = ci_t >= 2 ? 2 : 1; }
+    else { WCO = co_t < 3 ? co_t : 3; WCI = ci_t < 3 ? ci_t : 3; }
+    // wave arrangement: cover more channel tiles per workgroup first (fewer re-reads of the staged tiles), K-split the rest
+    f.gc = (co_t > WCO) ? 2 : 1;
+    f.gi = (ci_t > WCI) ? 2 : 1;
+    f.gk = 4 / (f.gc * f.gi);
+    f.co_blocks = ceil_div(co_t, f.gc * WCO); f.ci_blocks = ceil_div(ci_t, f.gi * WCI);
+    f.gd = f.gc * WCO * 2; f.gx = f.gi * WCI * 2;
+    f.PW = (f.TW - 1) * f.s + f.TB;
+    // pixel pitches: odd multiples of 16 B (+16) -- tr reads walk pixel rows
+    f.pitch_d = f.gd * 16 + 16; f.pitch_x = f.gx * 16 + 16;
+    int GDP = 1; while (GDP < f.gd) GDP <<= 1;
+    int GXP = 1; while (GXP < f.gx) GXP <<= 1;
+    if (ceil_div(128, 256 / GDP) > WG_DP || ceil_div(f.TH * f.PW, 256 / GXP) > WG_XP) return MFC_ERR_UNSUPPORTED;
+    const size_t ds = ((size_t)128 * f.pitch_d + 15) & ~(size_t)15, xs = ((size_t)f.TH * f.PW * f.pitch_x + 15) & ~(size_t)15;
+    f.off_x = (int)ds; f.buf_bytes = (int)(ds + xs); f.off_tab = 2 * f.buf_bytes;
+    f.G = d->N / d->images_per_group;
+    f.off_coef = f.off_tab + 128 * 4;
+    const size_t lds = (size_t)f.off_coef + (d->in_coef ? (size_t)f.G * 2 * f.gx * 8 * 4 : 0);
+    if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
+    const int Y = f.TA * f.co_blocks * f.ci_blocks;
+    int S = d->splits;
+    if (S <= 0) S = ceil_div(512, Y);
+    if (S > f.ntiles) S = f.ntiles;
+    if (S < 1) S = 1;
+    f.splits = S;
+#define WGF(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return wgrad_fast_launch<tb, a_, b_>(f, lds, Y, st);
+    WGF(3, 3, 3) WGF(3, 3, 2) WGF(3, 3, 1) WGF(3, 2, 3) WGF(3, 2, 2) WGF(3, 2, 1) WGF(3, 1, 3) WGF(3, 1, 2) WGF(3, 1, 1)
+    WGF(1, 3, 3) WGF(1, 3, 2) WGF(1, 3, 1) WGF(1, 2, 3) WGF(1, 2, 2) WGF(1, 2, 1) WGF(1, 1, 3) WGF(1, 1, 2) WGF(1, 1, 1)
+    WGF(11, 1, 2) WGF(11, 1, 1)
+#undef WGF
+    return MFC_ERR_UNSUPPORTED;
+}
+
 extern "C" int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream) {
     if (!d || !d->x || !d->dy || !d->dwp) return MFC_ERR_INVALID_ARG;
     if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
     if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin > d->Cin_p || d->Cout > d->Cout_p) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->TA <= 0 || d->TB <= 0 || d->in_stride < 1 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
+    {
+        int rcf = wgrad_fast(d, (hipStream_t)stream);
+        if (rcf != MFC_ERR_UNSUPPORTED) return rcf;
+    }
     const int esz = d->dtype == MFC_BF16 ? 2 : 4;
     WgradK k;
     k.x = (const char*)d->x; k.dy = (const char*)d->dy; k.dwp = d->dwp; k.in_coef = d->in_coef;

@@ -10,49 +10,60 @@
 #include "common.h"
 
 // ------------------------------------------------------------------ BN finalize
-__global__ __launch_bounds__(256) void bn_finalize_kernel(mfc_bnfin_desc d) {
-    for (int c = threadIdx.x; c < d.Cp; c += 256) {
-        if (c >= d.C) {
-            for (int g = 0; g < d.G; ++g)
-                for (int k = 0; k < 4; ++k) d.coef[((size_t)g * 4 + k) * d.Cp + c] = 0.f;
-            continue;
-        }
-        const float gamma = d.gamma[c], beta = d.beta[c];
-        if (d.training) {
-            float rm = d.running_mean[c], rv = d.running_var[c];
-            for (int g = 0; g < d.G; ++g) {
-                double s = 0.0, s2 = 0.0;
-                for (int r = 0; r < MFC_R; ++r) {
-                    s += (double)d.stats[(((size_t)r * d.G + g) * 2 + 0) * d.Cp + c];
-                    s2 += (double)d.stats[(((size_t)r * d.G + g) * 2 + 1) * d.Cp + c];
-                }
-                const double mean = s / (double)d.count;
-                double var = s2 / (double)d.count - mean * mean;
-                if (var < 0.0) var = 0.0;
-                const float rstd = (float)(1.0 / sqrt(var + (double)d.eps));
-                const float scale = gamma * rstd;
-                d.coef[((size_t)g * 4 + MFC_COEF_SCALE) * d.Cp + c] = scale;
-                d.coef[((size_t)g * 4 + MFC_COEF_SHIFT) * d.Cp + c] = beta - (float)mean * scale;
-                d.coef[((size_t)g * 4 + MFC_COEF_MEAN) * d.Cp + c] = (float)mean;
-                d.coef[((size_t)g * 4 + MFC_COEF_RSTD) * d.Cp + c] = rstd;
-                const double unb = d.count > 1.f ? var * (double)d.count / ((double)d.count - 1.0) : var;
-                rm = (1.f - d.momentum) * rm + d.momentum * (float)mean;
-                rv = (1.f - d.momentum) * rv + d.momentum * (float)unb;
-            }
-            d.running_mean[c] = rm; d.running_var[c] = rv;
-        } else {
-            const float mean = d.running_mean[c];
-            const float rstd = 1.0f / sqrtf(d.running_var[c] + d.eps);
-            const float scale = gamma * rstd;
-            for (int g = 0; g < d.G; ++g) {
-                d.coef[((size_t)g * 4 + MFC_COEF_SCALE) * d.Cp + c] = scale;
-                d.coef[((size_t)g * 4 + MFC_COEF_SHIFT) * d.Cp + c] = beta - mean * scale;
-                d.coef[((size_t)g * 4 + MFC_COEF_MEAN) * d.Cp + c] = mean;
-                d.coef[((size_t)g * 4 + MFC_COEF_RSTD) * d.Cp + c] = rstd;
-            }
-        }
+// sum of the R replica rows of one (group, stat, channel) cell: 32 independent loads in flight
+__device__ inline double replica_sum(const float* base, size_t stride) {
+    float p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < MFC_R; r += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] += base[(size_t)(r + k) * stride];
     }
-    if (d.training && d.num_batches_tracked && threadIdx.x == 0) *d.num_batches_tracked += d.G;
+    return ((double)p[0] + (double)p[1]) + ((double)p[2] + (double)p[3]) + ((double)p[4] + (double)p[5]) + ((double)p[6] + (double)p[7]);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(mfc_bnfin_desc d) {
+    const size_t rstride = (size_t)d.G * 2 * d.Cp;
+    // phase 1: one (group, channel) item per thread -> coefficients
+    for (int it = threadIdx.x; it < d.G * d.Cp; it += 256) {
+        const int g = it / d.Cp, c = it - g * d.Cp;
+        float* cf = d.coef + (size_t)g * 4 * d.Cp + c;
+        if (c >= d.C) { cf[0] = 0.f; cf[d.Cp] = 0.f; cf[2 * d.Cp] = 0.f; cf[3 * d.Cp] = 0.f; continue; }
+        const float gamma = d.gamma[c], beta = d.beta[c];
+        float mean, rstd;
+        if (d.training) {
+            const double s = replica_sum(d.stats + ((size_t)g * 2 + 0) * d.Cp + c, rstride);
+            const double s2 = replica_sum(d.stats + ((size_t)g * 2 + 1) * d.Cp + c, rstride);
+            const double m = s / (double)d.count;
+            double var = s2 / (double)d.count - m * m;
+            if (var < 0.0) var = 0.0;
+            mean = (float)m; rstd = (float)(1.0 / sqrt(var + (double)d.eps));
+            cf[2 * d.Cp] = mean; cf[3 * d.Cp] = rstd;
+        } else {
+            mean = d.running_mean[c]; rstd = 1.0f / sqrtf(d.running_var[c] + d.eps);
+            cf[2 * d.Cp] = mean; cf[3 * d.Cp] = rstd;
+        }
+        const float scale = gamma * rstd;
+        cf[0] = scale; cf[d.Cp] = beta - mean * scale;
+    }
+    if (!d.training) return;
+    __syncthreads();
+    // phase 2: running statistics, group after group (the reference calls base_model once per frame)
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+        float rm = d.running_mean[c], rv = d.running_var[c];
+        for (int g = 0; g < d.G; ++g) {
+            const float mean = d.coef[((size_t)g * 4 + MFC_COEF_MEAN) * d.Cp + c];
+            const float rstd = d.coef[((size_t)g * 4 + MFC_COEF_RSTD) * d.Cp + c];
+            double var = 1.0 / ((double)rstd * (double)rstd) - (double)d.eps;
+            if (var < 0.0) var = 0.0;
+            const double unb = d.count > 1.f ? var * (double)d.count / ((double)d.count - 1.0) : var;
+            rm = (1.f - d.momentum) * rm + d.momentum * mean;
+            rv = (1.f - d.momentum) * rv + d.momentum * (float)unb;
+        }
+        d.running_mean[c] = rm; d.running_var[c] = rv;
+    }
+    if (d.num_batches_tracked && threadIdx.x == 0) *d.num_batches_tracked += d.G;
 }
 
 extern "C" int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream) {
@@ -216,7 +227,7 @@ extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
     const int PPI = 256 / Cg;
     const int G = d->N / d->images_per_group;
     const long ppg = (long)d->images_per_group * d->y.H * d->y.W;
-    long want = ppg / 1024 + 1; if (want > 1024) want = 1024;       // blocks per group
+    long want = ppg / 192 + 1; if (want > 2048 / G + 1) want = 2048 / G + 1;       // blocks per group (~2048 in total)
     int ppb = (int)((ppg + want - 1) / want);
     ppb = ((ppb + PPI - 1) / PPI) * PPI;
     const int bx = (int)((ppg + ppb - 1) / ppb);
@@ -228,25 +239,30 @@ extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
 }
 
 __global__ __launch_bounds__(256) void bnbwd_finalize_kernel(mfc_bnbwdfin_desc d) {
-    for (int c = threadIdx.x; c < d.Cp; c += 256) {
-        double dg = 0.0, db = 0.0;
-        for (int g = 0; g < d.G; ++g) {
-            double s1 = 0.0, s2 = 0.0;
-            if (c < d.C)
-                for (int r = 0; r < MFC_R; ++r) {
-                    s1 += (double)d.bstats[(((size_t)r * d.G + g) * 2 + 0) * d.Cp + c];
-                    s2 += (double)d.bstats[(((size_t)r * d.G + g) * 2 + 1) * d.Cp + c];
-                }
-            d.bcoef[((size_t)g * 2 + 0) * d.Cp + c] = d.training ? (float)(s1 / (double)d.count) : 0.f;
-            d.bcoef[((size_t)g * 2 + 1) * d.Cp + c] = d.training ? (float)(s2 / (double)d.count) : 0.f;
-            db += s1; dg += s2;
+    __shared__ float sh[2][8][736];          // per (stat, group<=8, channel) sums for the gamma/beta gradients
+    const size_t rstride = (size_t)d.G * 2 * d.Cp;
+    for (int it = threadIdx.x; it < d.G * d.Cp; it += 256) {
+        const int g = it / d.Cp, c = it - g * d.Cp;
+        double s1 = 0.0, s2 = 0.0;
+        if (c < d.C) {
+            s1 = replica_sum(d.bstats + ((size_t)g * 2 + 0) * d.Cp + c, rstride);
+            s2 = replica_sum(d.bstats + ((size_t)g * 2 + 1) * d.Cp + c, rstride);
         }
-        if (c < d.C) { d.dgamma[c] = (float)dg; d.dbeta[c] = (float)db; }
+        d.bcoef[((size_t)g * 2 + 0) * d.Cp + c] = d.training ? (float)(s1 / (double)d.count) : 0.f;
+        d.bcoef[((size_t)g * 2 + 1) * d.Cp + c] = d.training ? (float)(s2 / (double)d.count) : 0.f;
+        sh[0][g][c] = (float)s1; sh[1][g][c] = (float)s2;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+        double db = 0.0, dg = 0.0;
+        for (int g = 0; g < d.G; ++g) { db += (double)sh[0][g][c]; dg += (double)sh[1][g][c]; }
+        d.dgamma[c] = (float)dg; d.dbeta[c] = (float)db;
     }
 }
 
 extern "C" int mfc_bnbwd_finalize(const mfc_bnbwdfin_desc* d, void* stream) {
     if (!d || !d->bstats || !d->bcoef || !d->dgamma || !d->dbeta || d->C <= 0 || d->C > d->Cp || d->G <= 0) return MFC_ERR_INVALID_ARG;
+    if (d->G > 8 || d->Cp > 736) return MFC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
