@@ -11,6 +11,8 @@
 // Replaces: the cuDNN wgrad triggered by loss.backward() (src/engine.py:70) for every nn.Conv2d
 // of models/hrnet.py and models/multiframe_model.py:191-201.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 static int g_wgrad_use_tr = 1;
 int mfc_conv_set_force_mt(int v);
@@ -215,8 +217,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
 //   * the dy tile and the input rows of the NEXT pixel tile are prefetched into registers while the MFMAs
 //     of the current one run from the other LDS buffer: one barrier per pixel tile.
 // ================================================================================================
-#define WG_DP 6     // max dy pieces (16 B) a thread prefetches per pixel tile
-#define WG_XP 7     // max input pieces
+// prefetch piece budgets (16-B pieces per thread per pixel tile): BIG = wide channel blocks (1 workgroup / CU, up to 512 VGPRs),
+// small = narrow blocks (2 workgroups / CU, <= 256 VGPRs).  Spilling here serialises the prefetch loads: never spill.
 
 struct WgradF {
     const char* x; const char* dy; float* dwp; const float* in_coef;
@@ -229,9 +231,10 @@ struct WgradF {
     int PW, pitch_d, pitch_x, buf_bytes, off_x, off_tab, off_coef, G;
 };
 
-template <int TB, int WCO, int WCI>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(WgradF p) {
+template <int TB, int WCO, int WCI, bool BIG>
+__global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_fast_kernel(WgradF p) {
     typedef bf16_t T;
+    constexpr int WG_DP = BIG ? 6 : 3, WG_XP = BIG ? 7 : 4;
     constexpr int E = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* xoff = (int*)(smem + p.off_tab);        // [128] patch byte offset of pixel (tap b = 0), 0 for padded pixels
@@ -256,26 +259,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(WgradF p) {
             coefs[i] = (ci0 + ch < p.Cin_p) ? p.in_coef[((size_t)g * 4 + w) * p.Cin_p + ci0 + ch] : 0.f;
         }
     }
-    // staging tables: dy piece i covers pixel tid/GDP + i*dstep, granule d_gi; x piece i covers patch pixel tid/GXP + i*xstep
-    int GDP = 1; while (GDP < p.gd) GDP <<= 1;
-    int GXP = 1; while (GXP < p.gx) GXP <<= 1;
-    const int d_gi = tid & (GDP - 1), dstep = 256 / GDP;
-    const int x_gi = tid & (GXP - 1), xstep = 256 / GXP;
-    const bool d_ok = d_gi < p.gd && (co0 + d_gi * E) < p.Cout_p;
-    const bool x_ok = x_gi < p.gx && (ci0 + x_gi * E) < p.Cin_p;
+    // staging tables (dense): piece idx = tid + i*256 -> (pixel, granule); packed as gi | px<<4 | ty<<12, or -1 (unused),
+    // bit 30 set = pixel row beyond the tile (stored as zeros)
     const int npx = p.TH * p.PW;
-    int dpyx[WG_DP], xpyx[WG_XP];
+    int dpk[WG_DP], xpk[WG_XP];
 #pragma unroll
     for (int i = 0; i < WG_DP; ++i) {
-        const int pp = tid / GDP + i * dstep;
+        const int idx = tid + i * 256;
+        const int pp = idx / p.gd, gi = idx - pp * p.gd;
         const int ty = pp / p.TW, tx = pp - ty * p.TW;
-        dpyx[i] = (pp < 128 && d_gi < p.gd) ? ((pp < p.TH * p.TW) ? ((ty << 16) | tx) : (1 << 30)) : -1;   // 1<<30: zero row
+        dpk[i] = (pp < 128) ? (gi | (tx << 4) | (ty << 12) | ((pp >= p.TH * p.TW || (co0 + gi * E) >= p.Cout_p) ? (1 << 30) : 0)) : -1;
     }
 #pragma unroll
     for (int i = 0; i < WG_XP; ++i) {
-        const int pix = tid / GXP + i * xstep;
+        const int idx = tid + i * 256;
+        const int pix = idx / p.gx, gi = idx - pix * p.gx;
         const int ty = pix / p.PW, px = pix - ty * p.PW;
-        xpyx[i] = (pix < npx && x_gi < p.gx) ? ((ty << 16) | px) : -1;
+        xpk[i] = (pix < npx) ? (gi | (px << 4) | (ty << 12) | (((ci0 + gi * E) >= p.Cin_p) ? (1 << 30) : 0)) : -1;
     }
 
     f32x4 acc[TB][WCO][WCI];
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(WgradF p) {
 
     uint4 dreg[WG_DP], xreg[WG_XP]; unsigned dmask = 0, xmask = 0;
     int x_grp = 0;
-    const bool xf = (p.in_coef != nullptr) && x_ok;
+    const bool xf = (p.in_coef != nullptr);
 
     auto tile_coords = [&](int tile, int& n, int& i0, int& j0) {
         const int txi = tile % p.tilesX; int r = tile / p.tilesX;
@@ -298,31 +298,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(WgradF p) {
     auto load_tile = [&](int tile) {
         int n, i0, j0; tile_coords(tile, n, i0, j0);
         dmask = 0; xmask = 0;
-        if (d_ok) {
-            const char* base = p.dy + ((size_t)n * p.Hout * p.Wout * p.Cout_p + co0) * sizeof(T) + (size_t)d_gi * 16;
+        x_grp = n / p.ipg;
+        const char* dbase = p.dy + ((size_t)n * p.Hout * p.Wout * p.Cout_p + co0) * sizeof(T);
 #pragma unroll
-            for (int i = 0; i < WG_DP; ++i) {
-                if (dpyx[i] >= 0 && dpyx[i] < (1 << 30)) {
-                    const int oi = i0 + (dpyx[i] >> 16), oj = j0 + (dpyx[i] & 0xffff);
-                    if (oi < p.Hout && oj < p.Wout) {
-                        dreg[i] = *(const uint4*)(base + (size_t)(oi * p.Wout + oj) * (p.Cout_p * (int)sizeof(T)));
-                        dmask |= 1u << i;
-                    }
+        for (int i = 0; i < WG_DP; ++i) {
+            if (dpk[i] >= 0 && !(dpk[i] & (1 << 30))) {
+                const int oi = i0 + (dpk[i] >> 12), oj = j0 + ((dpk[i] >> 4) & 0xff);
+                if (oi < p.Hout && oj < p.Wout) {
+                    dreg[i] = *(const uint4*)(dbase + (size_t)(oi * p.Wout + oj) * (p.Cout_p * (int)sizeof(T)) + (dpk[i] & 15) * 16);
+                    dmask |= 1u << i;
                 }
             }
         }
-        x_grp = n / p.ipg;
-        if (x_ok) {
-            const char* base = p.x + ((size_t)n * p.Hin * p.Win * p.Cin_p + ci0) * sizeof(T) + (size_t)x_gi * 16;
-            const int ihb = i0 * p.s + p.dh0 + a, iwb = j0 * p.s + p.dw0;
+        const char* xbase = p.x + ((size_t)n * p.Hin * p.Win * p.Cin_p + ci0) * sizeof(T);
+        const int ihb = i0 * p.s + p.dh0 + a, iwb = j0 * p.s + p.dw0;
 #pragma unroll
-            for (int i = 0; i < WG_XP; ++i) {
-                if (xpyx[i] >= 0) {
-                    const int ih = ihb + (xpyx[i] >> 16) * p.s, iw = iwb + (xpyx[i] & 0xffff);
-                    if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
-                        xreg[i] = *(const uint4*)(base + (size_t)(ih * p.Win + iw) * (p.Cin_p * (int)sizeof(T)));
-                        xmask |= 1u << i;
-                    }
+        for (int i = 0; i < WG_XP; ++i) {
+            if (xpk[i] >= 0 && !(xpk[i] & (1 << 30))) {
+                const int ih = ihb + (xpk[i] >> 12) * p.s, iw = iwb + ((xpk[i] >> 4) & 0xff);
+                if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
+                    xreg[i] = *(const uint4*)(xbase + (size_t)(ih * p.Win + iw) * (p.Cin_p * (int)sizeof(T)) + (xpk[i] & 15) * 16);
+                    xmask |= 1u << i;
                 }
             }
         }
@@ -331,35 +327,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(WgradF p) {
         char* Ds = buf; char* Xs = buf + p.off_x;
 #pragma unroll
         for (int i = 0; i < WG_DP; ++i) {
-            if (dpyx[i] >= 0) {
-                const int pp = tid / GDP + i * dstep;
-                *(uint4*)(Ds + pp * p.pitch_d + d_gi * 16) = (dmask & (1u << i)) ? dreg[i] : make_uint4(0, 0, 0, 0);
+            if (dpk[i] >= 0) {
+                const int row = ((dpk[i] >> 12) & 0xff) * p.TW + ((dpk[i] >> 4) & 0xff);     // = pixel index inside the tile
+                *(uint4*)(Ds + row * p.pitch_d + (dpk[i] & 15) * 16) = (dmask & (1u << i)) ? dreg[i] : make_uint4(0, 0, 0, 0);
             }
-        }
-        float sc[E], sh[E];
-        if (xf) {
-            const float* cf = coefs + (size_t)x_grp * 2 * (p.gx * 8) + x_gi * E;
-#pragma unroll
-            for (int e = 0; e < E; ++e) { sc[e] = cf[e]; sh[e] = cf[p.gx * 8 + e]; }
         }
 #pragma unroll
         for (int i = 0; i < WG_XP; ++i) {
-            if (xpyx[i] >= 0) {
+            if (xpk[i] >= 0) {
                 uint4 v = make_uint4(0, 0, 0, 0);
+                const int gi = xpk[i] & 15;
                 if (xmask & (1u << i)) {
                     v = xreg[i];
                     if (xf) {
+                        const float* cf = coefs + (size_t)x_grp * 2 * (p.gx * 8) + gi * E;
                         float f[E];
                         Gran<T>::unpack(v, f);
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
-                            float t = f[e] * sc[e] + sh[e];
+                            float t = f[e] * cf[e] + cf[p.gx * 8 + e];
                             f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
                         }
                         v = Gran<T>::pack(f);
                     }
                 }
-                *(uint4*)(Xs + ((xpyx[i] >> 16) * p.PW + (xpyx[i] & 0xffff)) * p.pitch_x + x_gi * 16) = v;
+                *(uint4*)(Xs + (((xpk[i] >> 12) & 0xff) * p.PW + ((xpk[i] >> 4) & 0xff)) * p.pitch_x + gi * 16) = v;
             }
         }
     };
@@ -409,20 +401,54 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(WgradF p) {
         if (nxt < p.ntiles) store_tile(smem + ((it + 1) & 1) * p.buf_bytes);
         __syncthreads();
     }
-    // ---- flush: D[row = co][col = ci]; lane holds col = lane&15, rows 4*(lane>>4)+r ----
+    // ---- K-split waves: tree-reduce the accumulators through LDS so that only one wave per tile set issues atomics ----
+    bool flusher = true;
+    if (p.gk > 1) {
+        constexpr int NTW = TB * WCO * WCI;
+        const int stride = p.gc * p.gi;                   // waves with equal (wc, wi) are `stride` apart
+        for (int half = p.gk >> 1; half >= 1; half >>= 1) {
+            __syncthreads();                              // staging buffers / previous round no longer read
+            const bool dump = flusher && wk >= half && wk < 2 * half;
+            const bool take = flusher && wk < half;
+            char* region = smem + (size_t)((wk % half) * stride + wc + p.gc * wi) * (NTW * 1024);
+            if (dump) {
+                int t = 0;
 #pragma unroll
-    for (int b = 0; b < TB; ++b)
+                for (int b = 0; b < TB; ++b)
 #pragma unroll
-        for (int i = 0; i < WCO; ++i)
+                    for (int i = 0; i < WCO; ++i)
 #pragma unroll
-            for (int j = 0; j < WCI; ++j) {
-                const int co = co0 + cow + i * 16 + (lane >> 4) * 4, ci = ci0 + ciw + j * 16 + (lane & 15);
-                if (co < p.Co16 && ci < p.Ci16) {
-                    float* o = p.dwp + ((size_t)(a * TB + b) * p.Co16 + co) * p.Ci16 + ci;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(o + (size_t)r * p.Ci16, acc[b][i][j][r]);
-                }
+                        for (int j = 0; j < WCI; ++j, ++t) *(f32x4*)(region + (t * 64 + lane) * 16) = acc[b][i][j];
+                flusher = false;
             }
+            __syncthreads();
+            if (take) {
+                int t = 0;
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+#pragma unroll
+                    for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                        for (int j = 0; j < WCI; ++j, ++t) acc[b][i][j] += *(const f32x4*)(region + (t * 64 + lane) * 16);
+            }
+        }
+    }
+    // ---- flush: D[row = co][col = ci]; lane holds col = lane&15, rows 4*(lane>>4)+r ----
+    if (flusher) {
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                for (int j = 0; j < WCI; ++j) {
+                    const int co = co0 + cow + i * 16 + (lane >> 4) * 4, ci = ci0 + ciw + j * 16 + (lane & 15);
+                    if (co < p.Co16 && ci < p.Ci16) {
+                        float* o = p.dwp + ((size_t)(a * TB + b) * p.Co16 + co) * p.Ci16 + ci;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(o + (size_t)r * p.Ci16, acc[b][i][j][r]);
+                    }
+                }
+    }
 }
 
 void mfc_choose_tile_wg(int Hl, int Wl, int& TH, int& TW) {
@@ -456,11 +482,11 @@ static int wgrad_launch(const WgradK& k, size_t lds, int Y, hipStream_t st) {
     return MFC_OK;
 }
 
-template <int TB, int WCO, int WCI>
+template <int TB, int WCO, int WCI, bool BIG>
 static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_fast_kernel<TB, WCO, WCI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on) {
@@ -468,7 +494,7 @@ static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st)
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
         mfc_prof_before(st, 1 * 16 + 8 + (TB == 1 ? 0 : TB == 3 ? 1 : 2), flops, bytes);
     }
-    hipLaunchKernelGGL((conv_wgrad_fast_kernel<TB, WCO, WCI>), dim3(f.splits, Y), dim3(256), lds, st, f);
+    hipLaunchKernelGGL((conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>), dim3(f.splits, Y), dim3(256), lds, st, f);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -501,22 +527,29 @@ static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st) {
     f.PW = (f.TW - 1) * f.s + f.TB;
     // pixel pitches: odd multiples of 16 B (+16) -- tr reads walk pixel rows
     f.pitch_d = f.gd * 16 + 16; f.pitch_x = f.gx * 16 + 16;
-    int GDP = 1; while (GDP < f.gd) GDP <<= 1;
-    int GXP = 1; while (GXP < f.gx) GXP <<= 1;
-    if (ceil_div(128, 256 / GDP) > WG_DP || ceil_div(f.TH * f.PW, 256 / GXP) > WG_XP) return MFC_ERR_UNSUPPORTED;
+    const int ndp = ceil_div(128 * f.gd, 256), nxp = ceil_div(f.TH * f.PW * f.gx, 256);
+    if (ndp > 6 || nxp > 7) return MFC_ERR_UNSUPPORTED;
+    const bool big = ndp > 3 || nxp > 4;
+    if (f.gd > 15 || f.gx > 15 || f.PW > 255 || f.TH > 255) return MFC_ERR_UNSUPPORTED;
     const size_t ds = ((size_t)128 * f.pitch_d + 15) & ~(size_t)15, xs = ((size_t)f.TH * f.PW * f.pitch_x + 15) & ~(size_t)15;
     f.off_x = (int)ds; f.buf_bytes = (int)(ds + xs); f.off_tab = 2 * f.buf_bytes;
     f.G = d->N / d->images_per_group;
     f.off_coef = f.off_tab + 128 * 4;
-    const size_t lds = (size_t)f.off_coef + (d->in_coef ? (size_t)f.G * 2 * f.gx * 8 * 4 : 0);
-    if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
+    size_t lds = (size_t)f.off_coef + (d->in_coef ? (size_t)f.G * 2 * f.gx * 8 * 4 : 0);
+    if (f.gk > 1) {      // room for the accumulator tree reduction: (gk/2) * gc * gi waves dump TB*WCO*WCI KiB each
+        const size_t need = (size_t)(f.gk / 2) * f.gc * f.gi * d->TB * WCO * WCI * 1024;
+        if (lds < need) lds = need;
+    }
+    if (lds > (big ? 160 : 80) * 1024) return MFC_ERR_UNSUPPORTED;
     const int Y = f.TA * f.co_blocks * f.ci_blocks;
     int S = d->splits;
-    if (S <= 0) S = ceil_div(512, Y);
+    if (S <= 0) S = ceil_div(big ? 256 : 512, Y);      // ~1 workgroup per CU-slot: each flushes its tiles once
     if (S > f.ntiles) S = f.ntiles;
     if (S < 1) S = 1;
     f.splits = S;
-#define WGF(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return wgrad_fast_launch<tb, a_, b_>(f, lds, Y, st);
+    static const bool dbg = getenv("MFC_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[wgrad fast] TB%d WCO%d WCI%d g=%dx%dx%d Y=%d S=%d lds=%zu tile %dx%d\n", d->TB, WCO, WCI, f.gc, f.gi, f.gk, Y, S, lds, f.TH, f.TW);
+#define WGF(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return big ? wgrad_fast_launch<tb, a_, b_, true>(f, lds, Y, st) : wgrad_fast_launch<tb, a_, b_, false>(f, lds, Y, st);
     WGF(3, 3, 3) WGF(3, 3, 2) WGF(3, 3, 1) WGF(3, 2, 3) WGF(3, 2, 2) WGF(3, 2, 1) WGF(3, 1, 3) WGF(3, 1, 2) WGF(3, 1, 1)
     WGF(1, 3, 3) WGF(1, 3, 2) WGF(1, 3, 1) WGF(1, 2, 3) WGF(1, 2, 2) WGF(1, 2, 1) WGF(1, 1, 3) WGF(1, 1, 2) WGF(1, 1, 1)
     WGF(11, 1, 2) WGF(11, 1, 1)
