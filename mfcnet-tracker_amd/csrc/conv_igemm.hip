@@ -127,24 +127,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         const int n = uc.n, i0 = uc.tyi * p.TH, j0 = uc.txi * p.TW;
         const int g0 = c * kg;
         pmask = 0;
-        if (p_gi < kg) {
-            if (p_xf) {
-                const float* cf = p.in_coef + (size_t)(n / p.ipg) * 4 * p.Cin_p + (g0 + p_gi) * E;
+        // Branch-free: every piece issues its load unconditionally from a clamped (always valid) address, so the compiler
+        // keeps the loads back to back and can count them (conditional loads force s_waitcnt vmcnt(0) before each one).
+        const int gic = min(p_gi, kg - 1);
+        if (p_xf) {
+            const float* cf = p.in_coef + (size_t)(n / p.ipg) * 4 * p.Cin_p + (g0 + gic) * E;
 #pragma unroll
-                for (int e = 0; e < E; ++e) { sc[e] = cf[e]; sh[e] = cf[p.Cin_p + e]; }
-            }
-            const int ih0 = i0 * p.s + p.dh0, iw0 = j0 * p.s + p.dw0;
-            const char* base = p.in + (size_t)n * p.Hin * p.Win * p.Cin_p * sizeof(T) + (size_t)(g0 + p_gi) * 16;
+            for (int e = 0; e < E; ++e) { sc[e] = cf[e]; sh[e] = cf[p.Cin_p + e]; }
+        }
+        const int ih0 = i0 * p.s + p.dh0, iw0 = j0 * p.s + p.dw0;
+        const char* base = p.in + (size_t)n * p.Hin * p.Win * p.Cin_p * sizeof(T) + (size_t)(g0 + gic) * 16;
 #pragma unroll
-            for (int i = 0; i < PMAX; ++i) {
-                if (pyx[i] >= 0) {
-                    const int ih = ih0 + (pyx[i] >> 16), iw = iw0 + (pyx[i] & 0xffff);
-                    if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
-                        preg[i] = *(const uint4*)(base + (size_t)(ih * p.Win + iw) * (p.Cin_p * (int)sizeof(T)));
-                        pmask |= 1u << i;
-                    }
-                }
-            }
+        for (int i = 0; i < PMAX; ++i) {
+            const int ih = ih0 + (pyx[i] >> 16), iw = iw0 + (pyx[i] & 0xffff);
+            const bool inr = pyx[i] >= 0 && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
+            const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
+            preg[i] = *(const uint4*)(base + (size_t)(ihc * p.Win + iwc) * (p.Cin_p * (int)sizeof(T)));
+            pmask |= (inr ? 1u : 0u) << i;
         }
     };
     auto store_patch = [&]() {

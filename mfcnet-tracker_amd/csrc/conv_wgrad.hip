@@ -299,28 +299,27 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_fast_kernel(Wgrad
         int n, i0, j0; tile_coords(tile, n, i0, j0);
         dmask = 0; xmask = 0;
         x_grp = n / p.ipg;
+        // Branch-free prefetch (see conv_igemm.hip load_patch): clamped addresses, unconditional loads, validity in a bit mask.
         const char* dbase = p.dy + ((size_t)n * p.Hout * p.Wout * p.Cout_p + co0) * sizeof(T);
 #pragma unroll
         for (int i = 0; i < WG_DP; ++i) {
-            if (dpk[i] >= 0 && !(dpk[i] & (1 << 30))) {
-                const int oi = i0 + (dpk[i] >> 12), oj = j0 + ((dpk[i] >> 4) & 0xff);
-                if (oi < p.Hout && oj < p.Wout) {
-                    dreg[i] = *(const uint4*)(dbase + (size_t)(oi * p.Wout + oj) * (p.Cout_p * (int)sizeof(T)) + (dpk[i] & 15) * 16);
-                    dmask |= 1u << i;
-                }
-            }
+            const int oi = i0 + ((dpk[i] >> 12) & 0xff), oj = j0 + ((dpk[i] >> 4) & 0xff);
+            const bool inr = dpk[i] >= 0 && !(dpk[i] & (1 << 30)) && oi < p.Hout && oj < p.Wout;
+            const int oic = min(oi, p.Hout - 1), ojc = min(oj, p.Wout - 1);
+            const int gic = ((co0 + (dpk[i] & 15) * E) < p.Cout_p) ? (dpk[i] & 15) : 0;
+            dreg[i] = *(const uint4*)(dbase + (size_t)(oic * p.Wout + ojc) * (p.Cout_p * (int)sizeof(T)) + gic * 16);
+            dmask |= (inr ? 1u : 0u) << i;
         }
         const char* xbase = p.x + ((size_t)n * p.Hin * p.Win * p.Cin_p + ci0) * sizeof(T);
         const int ihb = i0 * p.s + p.dh0 + a, iwb = j0 * p.s + p.dw0;
 #pragma unroll
         for (int i = 0; i < WG_XP; ++i) {
-            if (xpk[i] >= 0 && !(xpk[i] & (1 << 30))) {
-                const int ih = ihb + (xpk[i] >> 12) * p.s, iw = iwb + ((xpk[i] >> 4) & 0xff);
-                if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
-                    xreg[i] = *(const uint4*)(xbase + (size_t)(ih * p.Win + iw) * (p.Cin_p * (int)sizeof(T)) + (xpk[i] & 15) * 16);
-                    xmask |= 1u << i;
-                }
-            }
+            const int ih = ihb + ((xpk[i] >> 12) & 0xff) * p.s, iw = iwb + ((xpk[i] >> 4) & 0xff);
+            const bool inr = xpk[i] >= 0 && !(xpk[i] & (1 << 30)) && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
+            const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
+            const int gic = ((ci0 + (xpk[i] & 15) * E) < p.Cin_p) ? (xpk[i] & 15) : 0;
+            xreg[i] = *(const uint4*)(xbase + (size_t)(ihc * p.Win + iwc) * (p.Cin_p * (int)sizeof(T)) + gic * 16);
+            xmask |= (inr ? 1u : 0u) << i;
         }
     };
     auto store_tile = [&](char* buf) {
