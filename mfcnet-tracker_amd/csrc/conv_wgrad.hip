@@ -15,10 +15,12 @@
 #include <cstdlib>
 
 static int g_wgrad_use_tr = 1;
+static int g_wgrad_ksplit = 0;      // tuning: mfc_set_flag(3, 1) forces gc = gi = 1 (every wave holds all tiles, 4-way K split)
 int mfc_conv_set_force_mt(int v);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
+    if (id == 3) { g_wgrad_ksplit = value; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
 
@@ -516,10 +518,15 @@ static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st) {
     const int co_t = f.Co16 / 16, ci_t = f.Ci16 / 16;
     int WCO, WCI;
     if (d->TB == 11) { WCO = 1; WCI = ci_t >= 2 ? 2 : 1; }
-    else { WCO = co_t < 3 ? co_t : 3; WCI = ci_t < 3 ? ci_t : 3; }
-    // wave arrangement: cover more channel tiles per workgroup first (fewer re-reads of the staged tiles), K-split the rest
-    f.gc = (co_t > WCO) ? 2 : 1;
-    f.gi = (ci_t > WCI) ? 2 : 1;
+    else {      // balanced blocks of <= 3 tiles (4 tiles -> 2+2, not 3+1)
+        WCO = ceil_div(co_t, ceil_div(co_t, 3)); WCI = ceil_div(ci_t, ceil_div(ci_t, 3));
+    }
+    // wave arrangement.  3x3 / 11x11 taps: every wave holds ALL TB*WCO*WCI tiles of a 48x48-channel block and the 4 waves
+    // split the pixel axis (small staging footprint -> 2 workgroups per CU; measured 1.1-2.4x faster than tile-splitting).
+    // 1x1: few tiles per block otherwise -> spread 2x2 waves over cout/cin tiles.
+    const bool tile_split = (d->TB == 1) && !g_wgrad_ksplit;
+    f.gc = (tile_split && co_t > WCO) ? 2 : 1;
+    f.gi = (tile_split && ci_t > WCI) ? 2 : 1;
     f.gk = 4 / (f.gc * f.gi);
     f.co_blocks = ceil_div(co_t, f.gc * WCO); f.ci_blocks = ceil_div(ci_t, f.gi * WCI);
     f.gd = f.gc * WCO * 2; f.gx = f.gi * WCI * 2;

@@ -27,6 +27,8 @@ def main():
     what = sys.argv[2] if len(sys.argv) > 2 else "both"
     if len(sys.argv) > 3:
         L.lib.mfc_set_flag(2, int(sys.argv[3]))
+    if len(sys.argv) > 4:
+        L.lib.mfc_set_flag(3, int(sys.argv[4]))
     for (N, Cin, Cout, k, s, H, W) in SHAPES:
         pad = k // 2
         Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
