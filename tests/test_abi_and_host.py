@@ -1,0 +1,115 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/mfcnet_hip.h declares,
+the ctypes mirrors match the C struct sizes, descriptors are validated before any launch, and the host-side
+mirror of the reference interface (names, state_dict, errors) behaves like the reference's."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mfcnet_hip.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from mfcnet_amd import _lib
+    return _lib
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(mfc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    names = declared_functions()
+    assert len(names) >= 25
+    lib = C.CDLL(L.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
+    assert b"gfx950" in L.lib.mfc_version()
+
+
+def test_ctypes_mirrors_match_c_struct_sizes(L):
+    structs = {"mfc_op": L.Op, "mfc_conv_desc": L.ConvDesc, "mfc_wgrad_desc": L.WgradDesc, "mfc_pack_job": L.PackJob,
+               "mfc_unpack_job": L.UnpackJob, "mfc_bnfin_desc": L.BnFinDesc, "mfc_view": L.View, "mfc_combine_desc": L.CombineDesc,
+               "mfc_bnbwd_desc": L.BnBwdDesc, "mfc_bnbwdfin_desc": L.BnBwdFinDesc, "mfc_maskadd_desc": L.MaskAddDesc,
+               "mfc_headgather_desc": L.HeadDesc, "mfc_loss_desc": L.LossDesc, "mfc_conv_layout": L.ConvLayout,
+               "mfc_prof_result": L.ProfResult}
+    prog = '#include "mfcnet_hip.h"\n#include <stdio.h>\nint main(){' + "".join(
+        f'printf("{n} %zu\\n", sizeof({n}));' for n in structs) + "return 0;}"
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "s.c"), os.path.join(td, "s")
+        open(src, "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    for line in out.strip().splitlines():
+        name, size = line.split()
+        assert C.sizeof(structs[name]) == int(size), name
+    assert L.lib.mfc_op_size() == C.sizeof(L.Op)
+
+
+def test_descriptors_are_validated_before_any_launch(L):
+    assert L.lib.mfc_conv2d_fwd(C.byref(L.ConvDesc()), None) == -1
+    assert L.lib.mfc_conv2d_wgrad(C.byref(L.WgradDesc()), None) == -1
+    assert L.lib.mfc_bn_finalize(C.byref(L.BnFinDesc()), None) == -1
+    assert L.lib.mfc_combine_fwd(C.byref(L.CombineDesc()), None) == -1
+    assert L.lib.mfc_program_run(None, 3, None) == -1
+    d = L.ConvDesc(16, 16, 16, 0, 0, 0, L.BF16, 2, 8, 8, 12, 12, 8, 8, 16, 16, 8, 8, 3, 3, -1, -1, 1, 1, 1, 0, 0, 0, 2, 0, 0, 0)
+    assert L.lib.mfc_conv2d_fwd(C.byref(d), None) == -1            # channel pitch 12 is not a multiple of 8
+    d.Cin_p = 16
+    lay = L.conv_layout(d)                                          # geometry query needs no GPU
+    assert lay.TA == 3 and lay.NT16 == 16 and lay.bytes > 0 and lay.lds_bytes <= 80 * 1024
+
+
+def test_model_mirrors_reference_interface():
+    import mfcnet_amd as mfc
+    from oracle import mfcnet_oracle as O
+    args = SimpleNamespace(model_type="HRNetMulti-Large", num_classes=5, num_input_frames=3, pretrained=True,
+                           load_wts_base_model=None, add_optflow_inputs=True, add_depth_inputs=True)
+    m = mfc.get_multiframe_segmentation_model(args)
+    ref_keys = [t[0] for t in O.mfcnet_table("HRNetMulti-Large", 48, 5, 3, True, True)]
+    assert list(m.state_dict().keys()) == ref_keys                 # names AND order of the reference state_dict
+    sd = O.hashed_state(O.mfcnet_table("HRNetMulti-Large", 48, 5, 3, True, True))
+    m.load_state_dict(sd, strict=True)
+    assert torch.equal(m.base_model.last_layer[3].bias.detach(), sd["base_model.last_layer.3.bias"])
+    assert m.base_model.conv1.weight.data_ptr() == m._P.data_ptr()                # parameters are views of ONE arena
+    import numpy as np
+    n_ref = sum(int(np.prod(sh)) for _, sh, k in O.mfcnet_table('HRNetMulti-Large', 48, 5, 3, True, True) if k in ('conv_w', 'conv_b', 'bn_gamma', 'bn_beta'))
+    assert sum(p.numel() for p in m.parameters()) == n_ref
+    # the two optimizer groups of scripts/train_multiframe_detection.py:128-151 are two contiguous segments
+    seg = m.flat_segments()
+    assert seg["base_model"][1] == seg["multiframe_net"][0] and seg["multiframe_net"][1] == m._P.numel()
+    m.train(); m.base_model.eval()
+    assert m.multiframe_net.training and not m.base_model.training
+    args.model_type = "HRNetMulti-Basic"
+    mb = mfc.get_multiframe_segmentation_model(args)
+    assert "multiframe_net.grid" in mb.state_dict() and mb.state_dict()["multiframe_net.grid"].shape == (1, 2, 576, 720)
+    args.model_type = "UNet"
+    with pytest.raises(ValueError, match="not recognized"):        # models/__init__.py:86
+        mfc.get_multiframe_segmentation_model(args)
+    x = [torch.zeros(1, 3, 64, 96) for _ in range(3)]
+    with pytest.raises(mfc.MfcError):                               # no CPU fallback: the product path fails loudly
+        m(x, optflow=[torch.zeros(1, 2, 64, 96)] * 2, depth=[torch.zeros(1, 1, 64, 96)] * 3)
+
+
+def test_plan_builds_without_gpu():
+    """The whole forward+backward program (addresses, launch geometry, packed-weight layouts) is planned on the host."""
+    import mfcnet_amd as mfc
+    from mfcnet_amd import _lib as L
+    from mfcnet_amd.plan import Plan
+    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, optflow_inputs=True, depth_inputs=True, compute_dtype="bf16")
+    p = Plan(m, 2, 64, 96, True, True, True, True, True, torch.device("cpu"))
+    kinds = [o.kind for o in p.fwd_prog]
+    assert kinds.count(L.OP_CONV) == 311 and kinds.count(L.OP_BNFIN) == 309        # 307 + 4 convs
+    bk = [o.kind for o in p.bwd_prog]
+    assert bk.count(L.OP_WGRAD) == 311 and bk[-1] == L.OP_UNPACK
+    assert bk.count(L.OP_BNBWD_REDUCE) == bk.count(L.OP_BNBWD_APPLY) == 309
