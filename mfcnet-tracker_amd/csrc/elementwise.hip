@@ -23,54 +23,57 @@ __device__ inline double replica_sum(const float* base, size_t stride) {
     return ((double)p[0] + (double)p[1]) + ((double)p[2] + (double)p[3]) + ((double)p[4] + (double)p[5]) + ((double)p[6] + (double)p[7]);
 }
 
+// block = 64 channels x 4 group slots; grid = ceil(Cp / 64)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(mfc_bnfin_desc d) {
+    __shared__ float sm[8][64], sv[8][64];
     const size_t rstride = (size_t)d.G * 2 * d.Cp;
-    // phase 1: one (group, channel) item per thread -> coefficients
-    for (int it = threadIdx.x; it < d.G * d.Cp; it += 256) {
-        const int g = it / d.Cp, c = it - g * d.Cp;
-        float* cf = d.coef + (size_t)g * 4 * d.Cp + c;
-        if (c >= d.C) { cf[0] = 0.f; cf[d.Cp] = 0.f; cf[2 * d.Cp] = 0.f; cf[3 * d.Cp] = 0.f; continue; }
-        const float gamma = d.gamma[c], beta = d.beta[c];
-        float mean, rstd;
-        if (d.training) {
-            const double s = replica_sum(d.stats + ((size_t)g * 2 + 0) * d.Cp + c, rstride);
-            const double s2 = replica_sum(d.stats + ((size_t)g * 2 + 1) * d.Cp + c, rstride);
-            const double m = s / (double)d.count;
-            double var = s2 / (double)d.count - m * m;
-            if (var < 0.0) var = 0.0;
-            mean = (float)m; rstd = (float)(1.0 / sqrt(var + (double)d.eps));
-            cf[2 * d.Cp] = mean; cf[3 * d.Cp] = rstd;
-        } else {
-            mean = d.running_mean[c]; rstd = 1.0f / sqrtf(d.running_var[c] + d.eps);
-            cf[2 * d.Cp] = mean; cf[3 * d.Cp] = rstd;
+    const int cl = threadIdx.x & 63, gs = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    if (c < d.Cp) {
+        const bool real = c < d.C;
+        const float gamma = real ? d.gamma[c] : 0.f, beta = real ? d.beta[c] : 0.f;
+        for (int g = gs; g < d.G; g += 4) {
+            float* cf = d.coef + (size_t)g * 4 * d.Cp + c;
+            float mean = 0.f, rstd = 0.f, var = 0.f;
+            if (real) {
+                if (d.training) {
+                    const double s = replica_sum(d.stats + ((size_t)g * 2 + 0) * d.Cp + c, rstride);
+                    const double s2 = replica_sum(d.stats + ((size_t)g * 2 + 1) * d.Cp + c, rstride);
+                    const double m = s / (double)d.count;
+                    double v = s2 / (double)d.count - m * m;
+                    if (v < 0.0) v = 0.0;
+                    mean = (float)m; var = (float)v; rstd = (float)(1.0 / sqrt(v + (double)d.eps));
+                } else {
+                    mean = d.running_mean[c]; rstd = 1.0f / sqrtf(d.running_var[c] + d.eps);
+                }
+            }
+            const float scale = gamma * rstd;
+            cf[0] = scale; cf[d.Cp] = beta - mean * scale; cf[2 * d.Cp] = mean; cf[3 * d.Cp] = rstd;
+            sm[g][cl] = mean; sv[g][cl] = var;
         }
-        const float scale = gamma * rstd;
-        cf[0] = scale; cf[d.Cp] = beta - mean * scale;
     }
     if (!d.training) return;
     __syncthreads();
-    // phase 2: running statistics, group after group (the reference calls base_model once per frame)
-    for (int c = threadIdx.x; c < d.C; c += 256) {
+    // running statistics, group after group (the reference calls base_model once per frame)
+    if (gs == 0 && c < d.C) {
         float rm = d.running_mean[c], rv = d.running_var[c];
         for (int g = 0; g < d.G; ++g) {
-            const float mean = d.coef[((size_t)g * 4 + MFC_COEF_MEAN) * d.Cp + c];
-            const float rstd = d.coef[((size_t)g * 4 + MFC_COEF_RSTD) * d.Cp + c];
-            double var = 1.0 / ((double)rstd * (double)rstd) - (double)d.eps;
-            if (var < 0.0) var = 0.0;
+            const double var = (double)sv[g][cl];
             const double unb = d.count > 1.f ? var * (double)d.count / ((double)d.count - 1.0) : var;
-            rm = (1.f - d.momentum) * rm + d.momentum * mean;
+            rm = (1.f - d.momentum) * rm + d.momentum * sm[g][cl];
             rv = (1.f - d.momentum) * rv + d.momentum * (float)unb;
         }
         d.running_mean[c] = rm; d.running_var[c] = rv;
     }
-    if (d.num_batches_tracked && threadIdx.x == 0) *d.num_batches_tracked += d.G;
+    if (d.num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *d.num_batches_tracked += d.G;
 }
 
 extern "C" int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream) {
     if (!d || !d->coef || !d->gamma || !d->beta || !d->running_mean || !d->running_var) return MFC_ERR_INVALID_ARG;
     if (d->training && !d->stats) return MFC_ERR_INVALID_ARG;
     if (d->C <= 0 || d->C > d->Cp || d->G <= 0) return MFC_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
+    if (d->G > 8) return MFC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->Cp + 63) / 64), dim3(256), 0, (hipStream_t)stream, *d);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -148,18 +151,21 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
 }
 
 // ------------------------------------------------------------------ BN backward
-// mask value for a granule: mode 0 -> 1, mode 1 -> mask_src > 0, mode 2 -> y*scale+shift > 0
+// linear-pixel granule access (all views of one BN-backward call share N, H, W, so a pixel index addresses them all)
 template <typename T>
-__device__ inline void masked_grad(const mfc_bnbwd_desc& d, int n, int h, int w, int g, int grp, const float* yv, float* gm) {
+__device__ inline uint4 ld_lin(const mfc_view& v, long pix, int ch) {
+    return *(const uint4*)((const char*)v.ptr + ((size_t)pix * v.Cp + ch) * sizeof(T));
+}
+// masked gradient of one granule: mode 0 -> g, mode 1 -> g * [mask_src > 0], mode 2 -> g * [y*scale+shift > 0]
+template <typename T>
+__device__ inline void apply_mask(const mfc_bnbwd_desc& d, const uint4& mraw, const float* yv, const float* cf, float* gm) {
     constexpr int E = Gran<T>::E;
-    load_gran_f<T>(d.g, n, h, w, d.g.c_off + g * E, gm);
     if (d.mask_mode == 1) {
         float m[E];
-        load_gran_f<T>(d.mask, n, h, w, d.mask.c_off + g * E, m);
+        Gran<T>::unpack(mraw, m);
 #pragma unroll
         for (int e = 0; e < E; ++e) gm[e] = m[e] > 0.f ? gm[e] : 0.f;
     } else if (d.mask_mode == 2) {
-        const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + d.y.c_off + g * E;
 #pragma unroll
         for (int e = 0; e < E; ++e) gm[e] = (yv[e] * cf[e] + cf[d.y.Cp + e]) > 0.f ? gm[e] : 0.f;
     }
@@ -168,6 +174,7 @@ __device__ inline void masked_grad(const mfc_bnbwd_desc& d, int n, int h, int w,
 template <typename T>
 __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int Cg, int PPI, int pix_per_block, long pix_per_group) {
     constexpr int E = Gran<T>::E;
+    constexpr int U = 4;                       // pixels in flight per thread
     __shared__ float red[256 * 8 * 2];
     const int grp = blockIdx.y;
     const int gi = threadIdx.x % Cg, prow = threadIdx.x / Cg;
@@ -178,18 +185,30 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
     float mean[E], rstd[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) { mean[e] = cf[2 * d.y.Cp + e]; rstd[e] = cf[3 * d.y.Cp + e]; }
+    const long gbase = (long)grp * pix_per_group;
     const long p0 = (long)blockIdx.x * pix_per_block;
     long p1 = p0 + pix_per_block; if (p1 > pix_per_group) p1 = pix_per_group;
-    const long HW = (long)d.y.H * d.y.W;
-    for (long pp = p0 + prow; pp < p1; pp += PPI) {
-        const long gp = (long)grp * pix_per_group + pp;
-        const int n = (int)(gp / HW); const long r = gp - (long)n * HW;
-        const int h = (int)(r / d.y.W), w = (int)(r - (long)h * d.y.W);
-        float yv[E], gm[E];
-        load_gran_f<T>(d.y, n, h, w, d.y.c_off + gi * E, yv);
-        masked_grad<T>(d, n, h, w, gi, grp, yv, gm);
+    const int ych = d.y.c_off + gi * E, gch = d.g.c_off + gi * E, mch = d.mask.c_off + gi * E;
+    for (long pp = p0 + prow; pp < p1; pp += (long)U * PPI) {
+        uint4 yr[U], gr[U], mr[U];
 #pragma unroll
-        for (int e = 0; e < E; ++e) { s1[e] += gm[e]; s2[e] += gm[e] * (yv[e] - mean[e]) * rstd[e]; }
+        for (int u = 0; u < U; ++u) {
+            const long q = pp + (long)u * PPI;
+            const long qq = q < p1 ? q : p0 + prow;      // clamp: branch-free loads, masked below
+            yr[u] = ld_lin<T>(d.y, gbase + qq, ych);
+            gr[u] = ld_lin<T>(d.g, gbase + qq, gch);
+            if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, gbase + qq, mch);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pp + (long)u * PPI < p1) {
+                float yv[E], gm[E];
+                Gran<T>::unpack(yr[u], yv); Gran<T>::unpack(gr[u], gm);
+                apply_mask<T>(d, mr[u], yv, cf, gm);
+#pragma unroll
+                for (int e = 0; e < E; ++e) { s1[e] += gm[e]; s2[e] += gm[e] * (yv[e] - mean[e]) * rstd[e]; }
+            }
+        }
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) { red[(threadIdx.x * E + e) * 2] = s1[e]; red[(threadIdx.x * E + e) * 2 + 1] = s2[e]; }
@@ -239,31 +258,34 @@ extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
 }
 
 __global__ __launch_bounds__(256) void bnbwd_finalize_kernel(mfc_bnbwdfin_desc d) {
-    __shared__ float sh[2][8][736];          // per (stat, group<=8, channel) sums for the gamma/beta gradients
+    __shared__ float sh[2][8][64];           // per (stat, group <= 8, channel) sums for the gamma / beta gradients
     const size_t rstride = (size_t)d.G * 2 * d.Cp;
-    for (int it = threadIdx.x; it < d.G * d.Cp; it += 256) {
-        const int g = it / d.Cp, c = it - g * d.Cp;
-        double s1 = 0.0, s2 = 0.0;
-        if (c < d.C) {
-            s1 = replica_sum(d.bstats + ((size_t)g * 2 + 0) * d.Cp + c, rstride);
-            s2 = replica_sum(d.bstats + ((size_t)g * 2 + 1) * d.Cp + c, rstride);
+    const int cl = threadIdx.x & 63, gs = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    if (c < d.Cp) {
+        for (int g = gs; g < d.G; g += 4) {
+            double s1 = 0.0, s2 = 0.0;
+            if (c < d.C) {
+                s1 = replica_sum(d.bstats + ((size_t)g * 2 + 0) * d.Cp + c, rstride);
+                s2 = replica_sum(d.bstats + ((size_t)g * 2 + 1) * d.Cp + c, rstride);
+            }
+            d.bcoef[((size_t)g * 2 + 0) * d.Cp + c] = d.training ? (float)(s1 / (double)d.count) : 0.f;
+            d.bcoef[((size_t)g * 2 + 1) * d.Cp + c] = d.training ? (float)(s2 / (double)d.count) : 0.f;
+            sh[0][g][cl] = (float)s1; sh[1][g][cl] = (float)s2;
         }
-        d.bcoef[((size_t)g * 2 + 0) * d.Cp + c] = d.training ? (float)(s1 / (double)d.count) : 0.f;
-        d.bcoef[((size_t)g * 2 + 1) * d.Cp + c] = d.training ? (float)(s2 / (double)d.count) : 0.f;
-        sh[0][g][c] = (float)s1; sh[1][g][c] = (float)s2;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < d.C; c += 256) {
+    if (gs == 0 && c < d.C) {
         double db = 0.0, dg = 0.0;
-        for (int g = 0; g < d.G; ++g) { db += (double)sh[0][g][c]; dg += (double)sh[1][g][c]; }
+        for (int g = 0; g < d.G; ++g) { db += (double)sh[0][g][cl]; dg += (double)sh[1][g][cl]; }
         d.dgamma[c] = (float)dg; d.dbeta[c] = (float)db;
     }
 }
 
 extern "C" int mfc_bnbwd_finalize(const mfc_bnbwdfin_desc* d, void* stream) {
     if (!d || !d->bstats || !d->bcoef || !d->dgamma || !d->dbeta || d->C <= 0 || d->C > d->Cp || d->G <= 0) return MFC_ERR_INVALID_ARG;
-    if (d->G > 8 || d->Cp > 736) return MFC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
+    if (d->G > 8) return MFC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bnbwd_finalize_kernel, dim3((d->Cp + 63) / 64), dim3(256), 0, (hipStream_t)stream, *d);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -273,22 +295,23 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long
     constexpr int E = Gran<T>::E;
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int g = (int)(idx % Cg); long pix = idx / Cg;
-    const int w = (int)(pix % d.y.W); pix /= d.y.W;
-    const int h = (int)(pix % d.y.H); const int n = (int)(pix / d.y.H);
-    const int grp = n / d.images_per_group;
-    float yv[E], gm[E], o[E];
-    load_gran_f<T>(d.y, n, h, w, d.y.c_off + g * E, yv);
-    masked_grad<T>(d, n, h, w, g, grp, yv, gm);
+    const int g = (int)(idx % Cg); const long pix = idx / Cg;
+    const int grp = (int)(pix / ((long)d.images_per_group * d.y.H * d.y.W));
     const int c = d.y.c_off + g * E;
     const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + c;
     const float* bc = d.bcoef + (size_t)grp * 2 * d.y.Cp + c;
+    const uint4 yr = ld_lin<T>(d.y, pix, c), gr = ld_lin<T>(d.g, pix, d.g.c_off + g * E);
+    uint4 mr = make_uint4(0, 0, 0, 0);
+    if (d.mask_mode == 1) mr = ld_lin<T>(d.mask, pix, d.mask.c_off + g * E);
+    float yv[E], gm[E], o[E];
+    Gran<T>::unpack(yr, yv); Gran<T>::unpack(gr, gm);
+    apply_mask<T>(d, mr, yv, cf, gm);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const float yh = (yv[e] - cf[2 * d.y.Cp + e]) * cf[3 * d.y.Cp + e];
         o[e] = cf[e] * (gm[e] - bc[e] - yh * bc[d.y.Cp + e]);
     }
-    *(uint4*)((char*)d.dy.ptr + ((((size_t)n * d.dy.H + h) * d.dy.W + w) * d.dy.Cp + d.dy.c_off + g * E) * sizeof(T)) = Gran<T>::pack(o);
+    *(uint4*)((char*)d.dy.ptr + ((size_t)pix * d.dy.Cp + d.dy.c_off + g * E) * sizeof(T)) = Gran<T>::pack(o);
 }
 
 extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
