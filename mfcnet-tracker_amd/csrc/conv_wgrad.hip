@@ -452,6 +452,226 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_fast_kernel(Wgrad
     }
 }
 
+// ================================================================================================
+// Wave-private K-split path (3x3 / 11x11 taps): every wave of the workgroup walks its OWN sequence of
+// 32-pixel sub-tiles (one MFMA k-step each), stages them in its own double-buffered LDS slice and holds all
+// TB*WCO*WCI accumulator tiles of the workgroup's 48x48-channel block.  No workgroup barrier in the main loop:
+// a wave's LDS writes and reads are ordered by the LDS pipeline itself, so the 8 waves of a CU drift apart and
+// hide each other's global/LDS latency.  The four partial sums meet in an LDS tree reduction at the end.
+// ================================================================================================
+struct WgradW {
+    const char* x; const char* dy; float* dwp; const float* in_coef;
+    int N, Hin, Win, Cin_p, Hout, Wout, Cout_p;
+    int TA, TB, dh0, dw0, s, in_relu, ipg, G;
+    int TH, TW, tilesY, tilesX, ntiles, splits;     // sub-tile (TH*TW <= 32)
+    int Co16, Ci16, co_blocks, ci_blocks;
+    int gd, gx, PW, pitch_d, pitch_x, off_x, buf_bytes, wave_bytes, off_tab, off_coef;
+};
+
+template <int TB, int WCO, int WCI, int XP>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
+    typedef bf16_t T;
+    constexpr int E = 8;
+    constexpr int DP = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* xoff = (int*)(smem + p.off_tab);        // [32] patch byte offset of sub-tile pixel (tap b = 0)
+    float* coefs = (float*)(smem + p.off_coef);  // [G][2][gx*8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* wbase = smem + wave * p.wave_bytes;
+    int y = blockIdx.y;
+    const int ib = y % p.ci_blocks; y /= p.ci_blocks;
+    const int cb = y % p.co_blocks; const int a = y / p.co_blocks;
+    const int co0 = cb * WCO * 16, ci0 = ib * WCI * 16;
+
+    if (tid < 32) {
+        int ty = tid / p.TW, tx = tid - ty * p.TW;
+        xoff[tid] = (tid < p.TH * p.TW) ? (ty * p.PW + tx * p.s) * p.pitch_x : 0;
+    }
+    if (p.in_coef) {
+        const int nch = p.gx * 8;
+        for (int i = tid; i < p.G * 2 * nch; i += 256) {
+            const int ch = i % nch, w = (i / nch) & 1, g = i / (2 * nch);
+            coefs[i] = (ci0 + ch < p.Cin_p) ? p.in_coef[((size_t)g * 4 + w) * p.Cin_p + ci0 + ch] : 0.f;
+        }
+    }
+    // per-lane staging pieces: idx = lane + i*64 -> (pixel, granule); packed gi | px<<4 | ty<<12, bit 30 = zero row/granule
+    const int npx = p.TH * p.PW;
+    int dpk[DP], xpk[XP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+        const int idx = lane + i * 64;
+        const int pp = idx / p.gd, gi = idx - pp * p.gd;
+        const int ty = pp / p.TW, tx = pp - ty * p.TW;
+        dpk[i] = (pp < 32) ? (gi | (tx << 4) | (ty << 12) | ((pp >= p.TH * p.TW || (co0 + gi * E) >= p.Cout_p) ? (1 << 30) : 0)) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int idx = lane + i * 64;
+        const int pix = idx / p.gx, gi = idx - pix * p.gx;
+        const int ty = pix / p.PW, px = pix - ty * p.PW;
+        xpk[i] = (pix < npx) ? (gi | (px << 4) | (ty << 12) | (((ci0 + gi * E) >= p.Cin_p) ? (1 << 30) : 0)) : -1;
+    }
+
+    f32x4 acc[TB][WCO][WCI];
+#pragma unroll
+    for (int b = 0; b < TB; ++b)
+#pragma unroll
+        for (int i = 0; i < WCO; ++i)
+#pragma unroll
+            for (int j = 0; j < WCI; ++j) acc[b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 dreg[DP], xreg[XP]; unsigned dmask = 0, xmask = 0;
+    int x_grp = 0;
+    const bool xf = (p.in_coef != nullptr);
+
+    auto load_tile = [&](int tile) {
+        const int txi = tile % p.tilesX; int r = tile / p.tilesX;
+        const int tyi = r % p.tilesY; const int n = r / p.tilesY;
+        const int i0 = tyi * p.TH, j0 = txi * p.TW;
+        dmask = 0; xmask = 0;
+        x_grp = n / p.ipg;
+        const char* dbase = p.dy + ((size_t)n * p.Hout * p.Wout * p.Cout_p + co0) * sizeof(T);
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            const int oi = i0 + ((dpk[i] >> 12) & 0xff), oj = j0 + ((dpk[i] >> 4) & 0xff);
+            const bool inr = dpk[i] >= 0 && !(dpk[i] & (1 << 30)) && oi < p.Hout && oj < p.Wout;
+            const int oic = min(oi, p.Hout - 1), ojc = min(oj, p.Wout - 1);
+            const int gic = ((co0 + (dpk[i] & 15) * E) < p.Cout_p) ? (dpk[i] & 15) : 0;
+            dreg[i] = *(const uint4*)(dbase + (size_t)(oic * p.Wout + ojc) * (p.Cout_p * (int)sizeof(T)) + gic * 16);
+            dmask |= (inr ? 1u : 0u) << i;
+        }
+        const char* xbase = p.x + ((size_t)n * p.Hin * p.Win * p.Cin_p + ci0) * sizeof(T);
+        const int ihb = i0 * p.s + p.dh0 + a, iwb = j0 * p.s + p.dw0;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int ih = ihb + ((xpk[i] >> 12) & 0xff) * p.s, iw = iwb + ((xpk[i] >> 4) & 0xff);
+            const bool inr = xpk[i] >= 0 && !(xpk[i] & (1 << 30)) && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
+            const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
+            const int gic = ((ci0 + (xpk[i] & 15) * E) < p.Cin_p) ? (xpk[i] & 15) : 0;
+            xreg[i] = *(const uint4*)(xbase + (size_t)(ihc * p.Win + iwc) * (p.Cin_p * (int)sizeof(T)) + gic * 16);
+            xmask |= (inr ? 1u : 0u) << i;
+        }
+    };
+    auto store_tile = [&](char* buf) {
+        char* Ds = buf; char* Xs = buf + p.off_x;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            if (dpk[i] >= 0) {
+                const int row = ((dpk[i] >> 12) & 0xff) * p.TW + ((dpk[i] >> 4) & 0xff);
+                *(uint4*)(Ds + row * p.pitch_d + (dpk[i] & 15) * 16) = (dmask & (1u << i)) ? dreg[i] : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            if (xpk[i] >= 0) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int gi = xpk[i] & 15;
+                if (xmask & (1u << i)) {
+                    v = xreg[i];
+                    if (xf) {
+                        const float* cf = coefs + (size_t)x_grp * 2 * (p.gx * 8) + gi * E;
+                        float f[E];
+                        Gran<T>::unpack(v, f);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            float t = f[e] * cf[e] + cf[p.gx * 8 + e];
+                            f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
+                        }
+                        v = Gran<T>::pack(f);
+                    }
+                }
+                *(uint4*)(Xs + (((xpk[i] >> 12) & 0xff) * p.PW + ((xpk[i] >> 4) & 0xff)) * p.pitch_x + gi * 16) = v;
+            }
+        }
+    };
+
+    typedef __attribute__((address_space(3))) s16x4 lds_s4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    __syncthreads();                               // tables + coefficients visible
+    const int stride = p.splits * 4;
+    int tile = blockIdx.x * 4 + wave;
+    if (tile < p.ntiles) { load_tile(tile); store_tile(wbase); }
+    const int pr0 = 8 * (lane >> 4) + ((lane & 15) >> 2);
+    const int csub = (lane & 3) * 8;
+    const int xo0 = xoff[pr0] + csub, xo1 = xoff[pr0 + 4] + csub;
+    for (int it = 0; tile < p.ntiles; tile += stride, ++it) {
+        const int nxt = tile + stride;
+        if (nxt < p.ntiles) load_tile(nxt);
+        const char* Ds = wbase + (it & 1) * p.buf_bytes;
+        const char* Xs = Ds + p.off_x;
+        const char* dA0 = Ds + pr0 * p.pitch_d + csub;
+        const char* dA1 = dA0 + 4 * p.pitch_d;
+        bf16x8 af[WCO];
+#pragma unroll
+        for (int i = 0; i < WCO; ++i) {
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(dA0 + i * 32));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(dA1 + i * 32));
+            af[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            bf16x8 bfr[WCI];
+#pragma unroll
+            for (int j = 0; j < WCI; ++j) {
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Xs + xo0 + b * p.pitch_x + j * 32));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Xs + xo1 + b * p.pitch_x + j * 32));
+                bfr[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                for (int j = 0; j < WCI; ++j)
+                    acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[b][i][j], 0, 0, 0);
+        }
+        if (nxt < p.ntiles) store_tile(wbase + ((it + 1) & 1) * p.buf_bytes);
+    }
+    // ---- tree-reduce the four waves' accumulators through LDS, then one wave issues the atomics ----
+    constexpr int NTW = TB * WCO * WCI;
+    bool flusher = true;
+    for (int half = 2; half >= 1; half >>= 1) {
+        __syncthreads();
+        const bool dump = flusher && wave >= half && wave < 2 * half;
+        const bool take = flusher && wave < half;
+        char* region = smem + (size_t)(wave % half) * (NTW * 1024);
+        if (dump) {
+            int t = 0;
+#pragma unroll
+            for (int b = 0; b < TB; ++b)
+#pragma unroll
+                for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                    for (int j = 0; j < WCI; ++j, ++t) *(f32x4*)(region + (t * 64 + lane) * 16) = acc[b][i][j];
+            flusher = false;
+        }
+        __syncthreads();
+        if (take) {
+            int t = 0;
+#pragma unroll
+            for (int b = 0; b < TB; ++b)
+#pragma unroll
+                for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                    for (int j = 0; j < WCI; ++j, ++t) acc[b][i][j] += *(const f32x4*)(region + (t * 64 + lane) * 16);
+        }
+    }
+    if (flusher) {
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                for (int j = 0; j < WCI; ++j) {
+                    const int co = co0 + i * 16 + (lane >> 4) * 4, ci = ci0 + j * 16 + (lane & 15);
+                    if (co < p.Co16 && ci < p.Ci16) {
+                        float* o = p.dwp + ((size_t)(a * TB + b) * p.Co16 + co) * p.Ci16 + ci;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(o + (size_t)r * p.Ci16, acc[b][i][j][r]);
+                    }
+                }
+    }
+}
+
 void mfc_choose_tile_wg(int Hl, int Wl, int& TH, int& TW) {
     double best = -1; int bh = 8, bw = 16;
     for (int tw = 1; tw <= 128 && tw <= Wl; ++tw) {
@@ -563,13 +783,88 @@ static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st) {
     return MFC_ERR_UNSUPPORTED;
 }
 
+template <int TB, int WCO, int WCI, int XP>
+static int wgrad_wave_launch(const WgradW& f, size_t lds, int Y, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<TB, WCO, WCI, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (g_mfc_prof_on) {
+        const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB;
+        const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
+        mfc_prof_before(st, 1 * 16 + 8 + (TB == 3 ? 1 : 2), flops, bytes);
+    }
+    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TB, WCO, WCI, XP>), dim3(f.splits, Y), dim3(256), lds, st, f);
+    if (g_mfc_prof_on) mfc_prof_after(st);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+static void choose_subtile(int Hl, int Wl, int& TH, int& TW) {
+    double best = -1; int bh = 2, bw = 16;
+    for (int tw = 1; tw <= 32 && tw <= Wl; ++tw) {
+        int th = 32 / tw; if (th > Hl) th = Hl; if (th < 1) continue;
+        double tiles = (double)ceil_div(Hl, th) * ceil_div(Wl, tw);
+        double eff = (double)Hl * Wl / (tiles * 32.0);
+        double score = eff + ((tw % 8 == 0) ? 0.01 : 0.0) + 0.02 * (double)tw / (tw + 2.0);   // wide rows: less halo
+        if (score > best) { best = score; bh = th; bw = tw; }
+    }
+    TH = bh; TW = bw;
+}
+
+static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st) {
+    if (d->dtype != MFC_BF16 || !g_wgrad_use_tr || g_wgrad_ksplit == 2) return MFC_ERR_UNSUPPORTED;
+    if (d->TB != 3 && d->TB != 11) return MFC_ERR_UNSUPPORTED;
+    WgradW f;
+    f.x = (const char*)d->x; f.dy = (const char*)d->dy; f.dwp = d->dwp; f.in_coef = d->in_coef;
+    f.N = d->N; f.Hin = d->Hin; f.Win = d->Win; f.Cin_p = d->Cin_p; f.Hout = d->Hout; f.Wout = d->Wout; f.Cout_p = d->Cout_p;
+    f.TA = d->TA; f.TB = d->TB; f.dh0 = d->dh0; f.dw0 = d->dw0; f.s = d->in_stride; f.in_relu = d->in_relu; f.ipg = d->images_per_group;
+    f.G = d->N / d->images_per_group;
+    choose_subtile(d->Hout, d->Wout, f.TH, f.TW);
+    f.tilesY = ceil_div(d->Hout, f.TH); f.tilesX = ceil_div(d->Wout, f.TW);
+    f.ntiles = f.N * f.tilesY * f.tilesX;
+    f.Co16 = ceil_div(d->Cout, 16) * 16; f.Ci16 = ceil_div(d->Cin, 16) * 16;
+    const int co_t = f.Co16 / 16, ci_t = f.Ci16 / 16;
+    int WCO, WCI;
+    if (d->TB == 11) { WCO = 1; WCI = ci_t >= 2 ? 2 : 1; }
+    else { WCO = ceil_div(co_t, ceil_div(co_t, 3)); WCI = ceil_div(ci_t, ceil_div(ci_t, 3)); }
+    f.co_blocks = ceil_div(co_t, WCO); f.ci_blocks = ceil_div(ci_t, WCI);
+    f.gd = WCO * 2; f.gx = WCI * 2;
+    f.PW = (f.TW - 1) * f.s + f.TB;
+    f.pitch_d = f.gd * 16 + 16; f.pitch_x = f.gx * 16 + 16;
+    const int nxp = ceil_div(f.TH * f.PW * f.gx, 64);
+    if (ceil_div(32 * f.gd, 64) > 3 || nxp > 7 || f.PW > 255) return MFC_ERR_UNSUPPORTED;
+    const size_t ds = ((size_t)32 * f.pitch_d + 15) & ~(size_t)15, xs = ((size_t)f.TH * f.PW * f.pitch_x + 15) & ~(size_t)15;
+    f.off_x = (int)ds; f.buf_bytes = (int)(ds + xs); f.wave_bytes = 2 * f.buf_bytes;
+    size_t stage = (size_t)4 * f.wave_bytes;
+    const size_t need = (size_t)2 * d->TB * WCO * WCI * 1024;            // tree reduction scratch (2 dumping waves)
+    if (stage < need) stage = need;
+    f.off_tab = (int)stage; f.off_coef = f.off_tab + 32 * 4;
+    const size_t lds = (size_t)f.off_coef + (d->in_coef ? (size_t)f.G * 2 * f.gx * 8 * 4 : 0);
+    if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
+    const int Y = f.TA * f.co_blocks * f.ci_blocks;
+    int S = d->splits;
+    if (S <= 0) S = ceil_div(512, Y);
+    if (S * 4 > f.ntiles) S = ceil_div(f.ntiles, 4);
+    if (S < 1) S = 1;
+    f.splits = S;
+#define WGW(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return nxp <= 4 ? wgrad_wave_launch<tb, a_, b_, 4>(f, lds, Y, st) : wgrad_wave_launch<tb, a_, b_, 7>(f, lds, Y, st);
+    WGW(3, 3, 3) WGW(3, 3, 2) WGW(3, 3, 1) WGW(3, 2, 3) WGW(3, 2, 2) WGW(3, 2, 1) WGW(3, 1, 3) WGW(3, 1, 2) WGW(3, 1, 1)
+    WGW(11, 1, 2) WGW(11, 1, 1)
+#undef WGW
+    return MFC_ERR_UNSUPPORTED;
+}
+
 extern "C" int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream) {
     if (!d || !d->x || !d->dy || !d->dwp) return MFC_ERR_INVALID_ARG;
     if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
     if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin > d->Cin_p || d->Cout > d->Cout_p) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->TA <= 0 || d->TB <= 0 || d->in_stride < 1 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
     {
-        int rcf = wgrad_fast(d, (hipStream_t)stream);
+        int rcf = wgrad_wave(d, (hipStream_t)stream);
+        if (rcf != MFC_ERR_UNSUPPORTED) return rcf;
+        rcf = wgrad_fast(d, (hipStream_t)stream);
         if (rcf != MFC_ERR_UNSUPPORTED) return rcf;
     }
     const int esz = d->dtype == MFC_BF16 ? 2 : 4;
