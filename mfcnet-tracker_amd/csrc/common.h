@@ -27,6 +27,12 @@ __device__ inline unsigned bf16_bits(float f) {
     bf16_t b = (bf16_t)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return (unsigned)__builtin_bit_cast(unsigned short, b);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ inline unsigned pack_bf16x2(float lo, float hi) {      // one v_cvt_pk_bf16_f32
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 template <> struct Gran<bf16_t> {
     static constexpr int E = 8;
     __device__ static inline void unpack(const uint4& v, float* f) {
@@ -36,8 +42,7 @@ template <> struct Gran<bf16_t> {
         f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
     }
     __device__ static inline uint4 pack(const float* f) {
-        return make_uint4(bf16_bits(f[0]) | (bf16_bits(f[1]) << 16), bf16_bits(f[2]) | (bf16_bits(f[3]) << 16),
-                          bf16_bits(f[4]) | (bf16_bits(f[5]) << 16), bf16_bits(f[6]) | (bf16_bits(f[7]) << 16));
+        return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
     }
 };
 

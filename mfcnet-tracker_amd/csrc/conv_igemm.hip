@@ -137,13 +137,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         }
         const int ih0 = i0 * p.s + p.dh0, iw0 = j0 * p.s + p.dw0;
         const char* base = p.in + (size_t)n * p.Hin * p.Win * p.Cin_p * sizeof(T) + (size_t)(g0 + gic) * 16;
+        const int cs = p.Cin_p * (int)sizeof(T);
+        if (ih0 >= 0 && iw0 >= 0 && ih0 + p.PH <= p.Hin && iw0 + p.PW <= p.Win) {
+            // interior tile (uniform branch): no bounds arithmetic at all
+            const char* tb = base + (size_t)(ih0 * p.Win + iw0) * cs;
 #pragma unroll
-        for (int i = 0; i < PMAX; ++i) {
-            const int ih = ih0 + (pyx[i] >> 16), iw = iw0 + (pyx[i] & 0xffff);
-            const bool inr = pyx[i] >= 0 && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
-            const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
-            preg[i] = *(const uint4*)(base + (size_t)(ihc * p.Win + iwc) * (p.Cin_p * (int)sizeof(T)));
-            pmask |= (inr ? 1u : 0u) << i;
+            for (int i = 0; i < PMAX; ++i) {
+                const int pv = pyx[i] >= 0 ? pyx[i] : 0;
+                preg[i] = *(const uint4*)(tb + ((pv >> 16) * p.Win + (pv & 0xffff)) * cs);
+                pmask |= (pyx[i] >= 0 ? 1u : 0u) << i;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) {
+                const int ih = ih0 + (pyx[i] >> 16), iw = iw0 + (pyx[i] & 0xffff);
+                const bool inr = pyx[i] >= 0 && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
+                const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
+                preg[i] = *(const uint4*)(base + (size_t)(ihc * p.Win + iwc) * cs);
+                pmask |= (inr ? 1u : 0u) << i;
+            }
         }
     };
     auto store_patch = [&]() {
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                             for (int r = 0; r < 4; ++r) v[r] += ld_elem<T>(o + r);
                         }
                         if constexpr (BF) {
-                            *(uint2*)o = make_uint2(bf16_bits(v[0]) | (bf16_bits(v[1]) << 16), bf16_bits(v[2]) | (bf16_bits(v[3]) << 16));
+                            *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                         } else {
                             *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
                         }
