@@ -184,9 +184,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     // [TA][nchunks][Yblocks][nslots][NT16][16 B], i.e. one stage is ONE contiguous block = the LDS image
     auto dma_w = [&](const UC& uc, int c, int ag, char* wl) {
         const char* src = p.wp + (size_t)((ag * p.nchunks + c) * p.Yblocks + uc.yb) * p.stage_bytes + lane * 16;
-        for (int piece = wave; piece < p.npieces; piece += 4)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + piece * 1024), (lds_void_t*)(wl + piece * 1024), 16, 0, 0);
+        // Issued as inline asm: through the builtin hipcc assumes the DMA's LDS write may alias every later ds_read and
+        // drains it (s_waitcnt vmcnt(0)) before the compute loop, i.e. no overlap.  The buffers are disjoint by
+        // construction (double buffer); completion is awaited explicitly (dma_wait) before the stage-end barrier.
+        const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wl;
+        for (int piece = wave; piece < p.npieces; piece += 4) {
+            const char* g = src + piece * 1024;
+            const unsigned ldst = __builtin_amdgcn_readfirstlane(lbase + piece * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
+        }
     };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     // statistics: lanes -> row sums -> LDS (per wave) ; the cross-wave sum + atomics happen after the next barrier
     int red_par = 0; bool red_pending = false; int red_n0 = 0, red_grp = 0, red_rep = 0;
     auto stats_to_lds = [&](int n0, int grp, int rep) {
@@ -221,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     dma_w(uc, 0, 0, smem + p.off_w0);
     load_patch(uc, 0);
     store_patch();
+    dma_wait();
     __syncthreads();
 
     int tl = 0, c = 0, a = 0;          // current stage coordinates (a = tap-row group)
@@ -238,22 +249,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             const char* wl = smem + ((g & 1) ? p.off_w1 : p.off_w0);
             const char* pa = patch + a * p.TAS * p.PW * p.pitch;
             if constexpr (BF) {
+                // Software-pipelined, ping-pong unrolled by two: the LDS fragment reads of k-step k+1 are issued before the
+                // MFMAs of k-step k (loop-carried across the back edge, so the compiler cannot sink them next to their use).
                 const int nk = p.nslots >> 2;
                 const int gl = lane >> 4;
                 const char* wlb = wl + (gl * NT16 + (lane & 15)) * 16;
-                for (int ks = 0; ks < nk; ++ks) {
+                constexpr int KSS = 4 * NT16 * 16;
+                bf16x8 xa[MT], wa[NT], xb[MT], wb[NT];
+                auto ldx = [&](bf16x8* x, int ks) {
                     const int kq = ktab[ks * 4 + gl];
-                    bf16x8 xf[MT], wf[NT];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(pa + pbase[mt] + kq);
+                    for (int mt = 0; mt < MT; ++mt) x[mt] = *(const bf16x8*)(pa + pbase[mt] + kq);
+                };
+                auto ldw = [&](bf16x8* w, int ks) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(wlb + ks * (4 * NT16 * 16) + nt * 256);
+                    for (int nt = 0; nt < NT; ++nt) w[nt] = *(const bf16x8*)(wlb + ks * KSS + nt * 256);
+                };
+                auto mm = [&](const bf16x8* w, const bf16x8* x) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], x[mt], acc[mt][nt], 0, 0, 0);
+                };
+                ldx(xa, 0); ldw(wa, 0);
+                int ks = 0;
+                for (; ks + 2 <= nk; ks += 2) {
+                    ldx(xb, ks + 1); ldw(wb, ks + 1);
+                    mm(wa, xa);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT + 1, 0);     // DS reads of the next step first ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);         // ... then this step's MFMAs
+                    const int k2 = min(ks + 2, nk - 1);
+                    ldx(xa, k2); ldw(wa, k2);
+                    mm(wb, xb);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT + 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
                 }
+                if (ks < nk) mm(wa, xa);
             } else {
                 for (int q = 0; q < p.nslots; ++q) {
                     const int ko = ktab[q];
@@ -328,7 +360,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             __syncthreads();           // every wave has finished reading the current patch
             store_patch();
         }
-        __syncthreads();               // (drains the weight DMA of stage g+1: vmcnt(0) precedes the barrier)
+        dma_wait();                    // the weight DMA of stage g+1 has landed (this wave's pieces) ...
+        __syncthreads();               // ... and everybody's
         tl = tl2; c = c2; a = a2; uc = uc2;
     }
     if (red_pending) stats_flush();
@@ -421,7 +454,10 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
                 t.off_red = t.off_ktab + ((t.nslots * 4 + 15) & ~15);
                 const size_t l = (size_t)t.off_red + (size_t)2 * 4 * 2 * NT * 16 * 4;
                 const int pm = ceil_div(t.PH * t.PW, 256 / KGP);
-                if (l > 80 * 1024 || pm > (mt == 4 ? 6 : 10) || t.nslots > 256) continue;
+                // register budget (no spills: a spill in the prefetch path serialises it): wide N tiles keep fewer
+                // pixel tiles / prefetch pieces per thread
+                int pm_max = mt == 4 ? (NT == 6 ? 0 : NT == 4 ? 3 : 6) : (NT == 6 ? 4 : 10);
+                if (l > 80 * 1024 || pm > pm_max || t.nslots > 256) continue;
                 const double mf = (E == 8 ? t.nslots / 4 : t.nslots) * mt * NT;      // MFMAs per wave per stage
                 const double score = eff * fill * ((double)real / t.nslots) * (mf / (mf + 40.0)) * (mt == 4 ? 1.0 : 0.93);
                 if (score > best_score) { best_score = score; bk = t; bMT = mt; bPM = pm; blds = l; }
@@ -483,12 +519,18 @@ extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
 
 template <typename T, int NT>
 static int conv_dispatch(const ConvK& k, int MT, int PM, size_t lds, int grid, hipStream_t st) {
-    if (MT == 4) {
-        if (PM <= 6) return conv_launch<T, NT, 4, 6>(k, lds, grid, st);
+    if constexpr (NT == 6) {
+        if (MT == 2 && PM <= 4) return conv_launch<T, NT, 2, 4>(k, lds, grid, st);
         return MFC_ERR_UNSUPPORTED;
+    } else {
+        if (MT == 4) {
+            if (PM <= 3) return conv_launch<T, NT, 4, 3>(k, lds, grid, st);
+            if constexpr (NT <= 3) { if (PM <= 6) return conv_launch<T, NT, 4, 6>(k, lds, grid, st); }
+            return MFC_ERR_UNSUPPORTED;
+        }
+        if (PM <= 4) return conv_launch<T, NT, 2, 4>(k, lds, grid, st);
+        return conv_launch<T, NT, 2, 10>(k, lds, grid, st);
     }
-    if (PM <= 4) return conv_launch<T, NT, 2, 4>(k, lds, grid, st);
-    return conv_launch<T, NT, 2, 10>(k, lds, grid, st);
 }
 
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
