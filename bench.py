@@ -40,6 +40,7 @@ def cpu_baseline(width, T, H, W, steps=2):
     """The CPU oracle's training step on the host cores (bounded sample)."""
     from oracle import mfcnet_oracle as O
     torch.manual_seed(0)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))     # B=1 convolutions stop scaling (and oversubscribe) beyond ~32 threads
     sd = O.hashed_state(O.mfcnet_table("HRNetMulti-Large", width, 5, T, False, False))
     net = O.Net(sd, "HRNetMulti-Large", width, 5, T).train()
     opt = O.make_adam(net, 1e-4)
