@@ -260,7 +260,8 @@ typedef struct {
     int32_t warp;            /* 1: MultiFrameNetBasic warp (flow consumed, not concatenated) */
 } mfc_headgather_desc;
 int mfc_head_gather_fwd(const mfc_headgather_desc* d, void* stream);
-/* dlogits[t*B+b] (overwritten) = adjoint of the above wrt logits; `xh` is d(xh). */
+/* dlogits[t*B+b] (overwritten) = adjoint of the above wrt logits; `xh` is d(xh).  With warp != 0 the caller passes an
+ * fp32 scratch [B, H, W, (T-1)*nc] in depth[7] (the adjoint of grid_sample is a scatter; the call zeroes it). */
 int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, void* stream);
 
 /* ------------------------------------------------------------------------------------

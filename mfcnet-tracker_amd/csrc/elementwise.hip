@@ -596,7 +596,7 @@ static int head_check(const mfc_headgather_desc* d) {
     if (d->T < 1 || d->T > 8 || d->nc < 1 || d->nc > d->Lp || d->Cp % 8 || d->Cp > 40 || d->Lp % 8) return MFC_ERR_INVALID_ARG;
     int c = d->T * d->nc + ((!d->warp && d->flow[0]) ? 2 * (d->T - 1) : 0) + (d->depth[0] ? d->T : 0);
     if (c > d->Cp) return MFC_ERR_INVALID_ARG;
-    if (d->warp && !d->flow[0]) return MFC_ERR_INVALID_ARG;
+    if (d->warp && (!d->flow[0] || d->T > 7)) return MFC_ERR_INVALID_ARG;      // depth[7] carries the warp-backward scratch
     if (d->warp && (d->H > 576 || d->W > 720)) return MFC_ERR_UNSUPPORTED;   // reference raises here too (SURVEY A7 ii)
     return MFC_OK;
 }
@@ -612,13 +612,38 @@ extern "C" int mfc_head_gather_fwd(const mfc_headgather_desc* d, void* stream) {
     return MFC_OK;
 }
 
-// adjoint wrt the low-res logits.  No-warp: gather form.  Warp: the sample positions are data
-// dependent, so the adjoint is a scatter (fp32 atomics into a pre-zeroed fp32 scratch is avoided by
-// scattering straight into dlogits when T == float; bf16 uses the same kernel on an fp32 staging
-// buffer owned by the caller) -- only the gather form is built here; the warp adjoint scatters
-// with atomics into fp32 `dlogits` and therefore requires dtype == MFC_F32 staging.
+// adjoint wrt the low-res logits.  Without warp: one gather per low-res pixel.  With the MultiFrameNetBasic warp the
+// sample positions are data dependent, so the adjoint of grid_sample is a scatter: stage 1 scatters d(xh) of the warped
+// frames (t >= 1) into an fp32 full-resolution scratch dU[B,H,W,(T-1)*nc] with atomics (4 taps per pixel and channel),
+// stage 2 is the same x4 bilinear-adjoint gather, reading dU for t >= 1.
 template <typename T>
-__global__ __launch_bounds__(256) void head_gather_bwd_kernel(mfc_headgather_desc d, T* dl, long total) {
+__global__ __launch_bounds__(256) void head_warp_scatter_kernel(mfc_headgather_desc d, float* dU, long total) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one full-resolution pixel per thread
+    if (idx >= total) return;
+    const long HW = (long)d.H * d.W;
+    const int b = (int)(idx / HW); const long r = idx - (long)b * HW;
+    const int h = (int)(r / d.W), w = (int)(r - (long)h * d.W);
+    const int CU = (d.T - 1) * d.nc;
+    const T* g = (const T*)d.xh + (size_t)idx * d.Cp;
+    for (int t = 1; t < d.T; ++t) {
+        const float fx = d.flow[t - 1][((size_t)b * 2 + 0) * HW + r], fy = d.flow[t - 1][((size_t)b * 2 + 1) * HW + r];
+        float x, y; warp_pos(h, w, d.H, d.W, fx, fy, x, y);
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float ax = x - xf, ay = y - yf;
+        for (int dy_ = 0; dy_ < 2; ++dy_)
+            for (int dx_ = 0; dx_ < 2; ++dx_) {
+                const int yy = y0 + dy_, xx = x0 + dx_;
+                if (yy < 0 || yy >= d.H || xx < 0 || xx >= d.W) continue;
+                const float wt = (dy_ ? ay : 1.f - ay) * (dx_ ? ax : 1.f - ax);
+                float* o = dU + (((size_t)b * d.H + yy) * d.W + xx) * CU + (t - 1) * d.nc;
+                for (int k = 0; k < d.nc; ++k) atomicAdd(o + k, wt * ld_elem<T>(g + t * d.nc + k));
+            }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_gather_bwd_kernel(mfc_headgather_desc d, T* dl, const float* dU, long total) {
     constexpr int E = Gran<T>::E;
     long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one low-res pixel of one (t, b) map
     if (idx >= total) return;
@@ -631,7 +656,10 @@ __global__ __launch_bounds__(256) void head_gather_bwd_kernel(mfc_headgather_des
     int hlo, hhi, wlo, whi;
     adj_range(hs, d.Hs, d.H, hlo, hhi);
     adj_range(ws, d.Ws, d.W, wlo, whi);
+    const bool fromU = (dU != nullptr) && t > 0;
+    const int CU = (d.T - 1) * d.nc;
     const T* G = (const T*)d.xh + (size_t)b * d.H * d.W * d.Cp + t * d.nc;
+    const float* GU = fromU ? dU + (size_t)b * d.H * d.W * CU + (t - 1) * d.nc : nullptr;
     for (int hh = hlo; hh <= hhi; ++hh) {
         int h0, h1; float lh;
         bilin_src(hh, d.Hs, d.H, h0, h1, lh);
@@ -642,8 +670,13 @@ __global__ __launch_bounds__(256) void head_gather_bwd_kernel(mfc_headgather_des
             bilin_src(ww, d.Ws, d.W, w0, w1, lw);
             const float wt = wh * ((w0 == ws ? 1.f - lw : 0.f) + (w1 == ws ? lw : 0.f));
             if (wt == 0.f) continue;
-            const T* gp = G + ((size_t)hh * d.W + ww) * d.Cp;
-            for (int k = 0; k < d.nc; ++k) acc[k] += wt * ld_elem<T>(gp + k);
+            if (fromU) {
+                const float* gp = GU + ((size_t)hh * d.W + ww) * CU;
+                for (int k = 0; k < d.nc; ++k) acc[k] += wt * gp[k];
+            } else {
+                const T* gp = G + ((size_t)hh * d.W + ww) * d.Cp;
+                for (int k = 0; k < d.nc; ++k) acc[k] += wt * ld_elem<T>(gp + k);
+            }
         }
     }
     float o[8];
@@ -659,12 +692,22 @@ __global__ __launch_bounds__(256) void head_gather_bwd_kernel(mfc_headgather_des
 extern "C" int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, void* stream) {
     int rc = head_check(d); if (rc < 0) return rc;
     if (!dlogits || d->nc > 8) return MFC_ERR_INVALID_ARG;
-    if (d->warp) return MFC_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    float* dU = nullptr;
+    if (d->warp && d->T > 1) {
+        dU = (float*)d->depth[7];                  // fp32 scratch [B, H, W, (T-1)*nc] supplied by the caller (see header)
+        if (!dU) return MFC_ERR_INVALID_ARG;
+        const size_t bytes = (size_t)d->B * d->H * d->W * (d->T - 1) * d->nc * sizeof(float);
+        if (hipMemsetAsync(dU, 0, bytes, st) != hipSuccess) return MFC_ERR_LAUNCH;
+        const long tot = (long)d->B * d->H * d->W;
+        const int blk = (int)((tot + 255) / 256);
+        if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_warp_scatter_kernel<bf16_t>, dim3(blk), dim3(256), 0, st, *d, dU, tot);
+        else hipLaunchKernelGGL(head_warp_scatter_kernel<float>, dim3(blk), dim3(256), 0, st, *d, dU, tot);
+    }
     const long total = (long)d->T * d->B * d->Hs * d->Ws;
     const int blocks = (int)((total + 255) / 256);
-    hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, (bf16_t*)dlogits, total);
-    else hipLaunchKernelGGL(head_gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, (float*)dlogits, total);
+    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, (bf16_t*)dlogits, (const float*)dU, total);
+    else hipLaunchKernelGGL(head_gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, (float*)dlogits, (const float*)dU, total);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

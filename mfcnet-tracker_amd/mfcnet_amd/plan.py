@@ -430,6 +430,8 @@ class Plan:
                 C.memmove(C.byref(hb.d), C.byref(hd), C.sizeof(L.HeadDesc))
                 hb.d.xh = self.grad_of(xh).ptr
                 hb.dlogits = self.grad_of(logits).ptr
+                if hb.d.warp:          # fp32 scratch for the scatter form of the grid_sample adjoint
+                    hb.d.depth[7] = self._alloc("misc", self.B * self.H * self.W * (self.T - 1) * self.nc * 4)
                 self.bwd.append((L.OP_HEAD_BWD, hb))
                 logits.grad_init = True
             elif kind == "bnfin":

@@ -61,8 +61,6 @@ def dev(lst):
 
 def run_golden(mfc, name, fuse_bn=True):
     cfg, z = load_case(name)
-    if "Basic" in cfg["model_type"] and cfg["optflow"] and cfg["mode"] != "eval":
-        pytest.skip("warp adjoint (HRNetMulti-Basic + flow, training) is a next-round row")
     m = build(mfc, cfg, fuse_bn=fuse_bn)
     set_mode(m, cfg["mode"])
     frames, flows, depths, mask = case_inputs(cfg)

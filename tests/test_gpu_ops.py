@@ -316,6 +316,53 @@ def test_head_gather_fwd_bwd(M, dtype, flow, depth):
     assert relerr(ops.to_nchw(dl, nc).cpu(), lg.grad) < TOL[dtype] * 2
 
 
+@pytest.mark.parametrize("depth", [False, True])
+def test_head_gather_warp_fwd_bwd(M, depth):
+    """MultiFrameNetBasic flow warp (multiframe_model.py:89-170, incl. the 576x720 grid quirk) fused into the head gather:
+    forward against F.grid_sample on the up-sampled logits, backward against autograd."""
+    _, L, ops = M
+    B, T, nc, Hs, Ws = 2, 3, 5, 12, 20
+    H, W = 4 * Hs, 4 * Ws
+    dtype = torch.float32
+    lg = rnd(dtype, T * B, nc, Hs, Ws, seed=50).requires_grad_(True)
+    fl = [rnd(dtype, B, 2, H, W, seed=51 + i, scale=3.0) for i in range(T - 1)]
+    dp = [rnd(dtype, B, 1, H, W, seed=55 + i).abs() for i in range(T)] if depth else []
+    gy, gx = torch.meshgrid(torch.arange(0, 576), torch.arange(0, 720), indexing="ij")
+    grid = torch.stack((2.0 * gx / 719 - 1.0, 2.0 * gy / 575 - 1.0), 0).float().unsqueeze(0)[:, :, :H, :W]
+
+    def warp(m, flow):
+        g = (grid + torch.stack((flow[:, 0] / ((W - 1) / 2.0), flow[:, 1] / ((H - 1) / 2.0)), 1)).permute(0, 2, 3, 1)
+        return F.grid_sample(m, g, mode="bilinear", padding_mode="zeros", align_corners=True)
+
+    ups = [F.interpolate(lg[t * B:(t + 1) * B], size=(H, W), mode="bilinear", align_corners=False) for t in range(T)]
+    segs = [ups[0]] + [warp(ups[t], fl[t - 1]) for t in range(1, T)]
+    deps = ([dp[0]] + [warp(dp[t], fl[t - 1]) for t in range(1, T)]) if depth else []
+    ref = torch.cat(segs + deps, 1)
+    cin = ref.shape[1]
+    Cp = (cin + 7) // 8 * 8
+    tl = ops.to_nhwc(lg.detach(), dtype)
+    xh = torch.zeros(B, H, W, Cp, dtype=dtype, device="cuda")
+    fld, dpd = [f.cuda() for f in fl], [p.cuda() for p in dp]
+    d = L.HeadDesc()
+    d.logits, d.xh = tl.data_ptr(), xh.data_ptr()
+    for i, f in enumerate(fld):
+        d.flow[i] = f.data_ptr()
+    for i, p in enumerate(dpd):
+        d.depth[i] = p.data_ptr()
+    d.dtype, d.B, d.T, d.nc, d.Hs, d.Ws, d.Lp, d.H, d.W, d.Cp, d.warp = ops.dt_of(tl), B, T, nc, Hs, Ws, 8, H, W, Cp, 1
+    L.call(L.lib.mfc_head_gather_fwd, d)
+    assert relerr(ops.to_nchw(xh, cin).cpu(), ref.detach()) < 2e-4
+    g = rnd(dtype, B, cin, H, W, seed=60)
+    ref.backward(g)
+    tg = ops.to_nhwc(g, dtype)
+    dl = torch.zeros_like(tl)
+    scratch = torch.empty(B * H * W * (T - 1) * nc, dtype=torch.float32, device="cuda")
+    d.xh = tg.data_ptr()
+    d.depth[7] = scratch.data_ptr()
+    L.check(L.lib.mfc_head_gather_bwd(C.byref(d), dl.data_ptr(), L.stream_ptr()))
+    assert relerr(ops.to_nchw(dl, nc).cpu(), lg.grad) < 5e-4
+
+
 def test_loss_fwd_bwd(M):
     mfc, L, ops = M
     from oracle import mfcnet_oracle as O
