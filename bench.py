@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,13 +77,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    local = local % torch.cuda.device_count()          # (gloo rehearsal: several ranks may share one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     import mfcnet_amd as mfc
     from mfcnet_amd import _lib as L
