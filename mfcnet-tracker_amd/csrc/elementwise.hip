@@ -130,6 +130,52 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, lo
     *(uint4*)((char*)d.out.ptr + ((((size_t)n * d.out.H + h) * d.out.W + w) * d.out.Cp + d.out.c_off + g * E) * sizeof(T)) = Gran<T>::pack(acc);
 }
 
+// all sources at the output resolution (residual blocks, BN materialisation): linear pixel index, 2 granules per thread
+template <typename T>
+__global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, long total, int Cg) {
+    constexpr int E = Gran<T>::E;
+    constexpr int U = 2;
+    const long base = ((long)blockIdx.x * 256) * U + threadIdx.x;
+    const long ppg = (long)d.images_per_group * d.out.H * d.out.W;
+    uint4 r[U][4]; long pix[U]; int gq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        long idx = base + (long)u * 256;
+        if (idx >= total) idx = total - 1;
+        gq[u] = (int)(idx % Cg); pix[u] = idx / Cg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < d.nsrc) r[u][k] = *(const uint4*)((const char*)d.src[k].ptr + ((size_t)pix[u] * d.src[k].Cp + d.src[k].c_off + gq[u] * E) * sizeof(T));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (base + (long)u * 256 >= total) break;
+        const int grp = (int)(pix[u] / ppg);
+        float acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < d.nsrc) {
+                float f[E];
+                Gran<T>::unpack(r[u][k], f);
+                if (d.src[k].coef) {
+                    const float* cf = (const float*)d.src[k].coef + (size_t)grp * 4 * d.src[k].Cp + d.src[k].c_off + gq[u] * E;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) f[e] = f[e] * cf[e] + cf[d.src[k].Cp + e];
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] += f[e];
+            }
+        }
+        if (d.relu) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        }
+        *(uint4*)((char*)d.out.ptr + ((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(acc);
+    }
+}
+
 static bool view_ok(const mfc_view& v, int E) { return v.ptr && v.H > 0 && v.W > 0 && v.Cp % 8 == 0 && v.c_off % E == 0; }
 
 extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
@@ -144,6 +190,15 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
     const long total = (long)d->N * d->out.H * d->out.W * Cg;
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
+    bool same = true;
+    for (int k = 0; k < d->nsrc; ++k) same = same && d->src[k].H == d->out.H && d->src[k].W == d->out.W;
+    if (same) {
+        const int b2 = (int)((total + 511) / 512);
+        if (d->dtype == MFC_BF16) hipLaunchKernelGGL(combine_same_kernel<bf16_t>, dim3(b2), dim3(256), 0, st, *d, total, Cg);
+        else hipLaunchKernelGGL(combine_same_kernel<float>, dim3(b2), dim3(256), 0, st, *d, total, Cg);
+        MFC_CHECK_LAUNCH();
+        return MFC_OK;
+    }
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(combine_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
     else hipLaunchKernelGGL(combine_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
     MFC_CHECK_LAUNCH();
@@ -293,25 +348,36 @@ extern "C" int mfc_bnbwd_finalize(const mfc_bnbwdfin_desc* d, void* stream) {
 template <typename T>
 __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long total, int Cg) {
     constexpr int E = Gran<T>::E;
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % Cg); const long pix = idx / Cg;
-    const int grp = (int)(pix / ((long)d.images_per_group * d.y.H * d.y.W));
-    const int c = d.y.c_off + g * E;
-    const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + c;
-    const float* bc = d.bcoef + (size_t)grp * 2 * d.y.Cp + c;
-    const uint4 yr = ld_lin<T>(d.y, pix, c), gr = ld_lin<T>(d.g, pix, d.g.c_off + g * E);
-    uint4 mr = make_uint4(0, 0, 0, 0);
-    if (d.mask_mode == 1) mr = ld_lin<T>(d.mask, pix, d.mask.c_off + g * E);
-    float yv[E], gm[E], o[E];
-    Gran<T>::unpack(yr, yv); Gran<T>::unpack(gr, gm);
-    apply_mask<T>(d, mr, yv, cf, gm);
+    constexpr int U = 4;                                   // granules in flight per thread
+    const long base = ((long)blockIdx.x * 256) * U + threadIdx.x;
+    const long ppg = (long)d.images_per_group * d.y.H * d.y.W;
+    uint4 yr[U], gr[U], mr[U]; long pix[U]; int gq[U];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const float yh = (yv[e] - cf[2 * d.y.Cp + e]) * cf[3 * d.y.Cp + e];
-        o[e] = cf[e] * (gm[e] - bc[e] - yh * bc[d.y.Cp + e]);
+    for (int u = 0; u < U; ++u) {
+        long idx = base + (long)u * 256;
+        if (idx >= total) idx = total - 1;                 // clamp: branch-free loads, masked at the store
+        gq[u] = (int)(idx % Cg); pix[u] = idx / Cg;
+        yr[u] = ld_lin<T>(d.y, pix[u], d.y.c_off + gq[u] * E);
+        gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
+        if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
     }
-    *(uint4*)((char*)d.dy.ptr + ((size_t)pix * d.dy.Cp + d.dy.c_off + g * E) * sizeof(T)) = Gran<T>::pack(o);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (base + (long)u * 256 >= total) break;
+        const int grp = (int)(pix[u] / ppg);
+        const int c = d.y.c_off + gq[u] * E;
+        const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + c;
+        const float* bc = d.bcoef + (size_t)grp * 2 * d.y.Cp + c;
+        float yv[E], gm[E], o[E];
+        Gran<T>::unpack(yr[u], yv); Gran<T>::unpack(gr[u], gm);
+        apply_mask<T>(d, mr[u], yv, cf, gm);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float yh = (yv[e] - cf[2 * d.y.Cp + e]) * cf[3 * d.y.Cp + e];
+            o[e] = cf[e] * (gm[e] - bc[e] - yh * bc[d.y.Cp + e]);
+        }
+        *(uint4*)((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(o);
+    }
 }
 
 extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
@@ -319,7 +385,7 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
     if (!d->bcoef || !view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     const long total = (long)d->N * d->y.H * d->y.W * Cg;
-    const int blocks = (int)((total + 255) / 256);
+    const int blocks = (int)((total + 1023) / 1024);
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
     else hipLaunchKernelGGL(bnbwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
@@ -393,6 +459,43 @@ __global__ __launch_bounds__(256) void mask_add_kernel(mfc_maskadd_desc d, long 
     *(uint4*)o = Gran<T>::pack(acc);
 }
 
+// same-resolution fast path: linear pixel index, 4 granules in flight per thread
+template <typename T>
+__global__ __launch_bounds__(256) void mask_add_same_kernel(mfc_maskadd_desc d, long total, int Cg) {
+    constexpr int E = Gran<T>::E;
+    constexpr int U = 4;
+    const long base = ((long)blockIdx.x * 256) * U + threadIdx.x;
+    uint4 gr[U], mr[U], dr[U]; long pix[U]; int gq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        long idx = base + (long)u * 256;
+        if (idx >= total) idx = total - 1;
+        gq[u] = (int)(idx % Cg); pix[u] = idx / Cg;
+        gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
+        if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
+        if (d.accumulate) dr[u] = ld_lin<T>(d.dst, pix[u], d.dst.c_off + gq[u] * E);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (base + (long)u * 256 >= total) break;
+        float gv[E];
+        Gran<T>::unpack(gr[u], gv);
+        if (d.mask_mode == 1) {
+            float m[E];
+            Gran<T>::unpack(mr[u], m);
+#pragma unroll
+            for (int e = 0; e < E; ++e) gv[e] = m[e] > 0.f ? gv[e] : 0.f;
+        }
+        if (d.accumulate) {
+            float o[E];
+            Gran<T>::unpack(dr[u], o);
+#pragma unroll
+            for (int e = 0; e < E; ++e) gv[e] += o[e];
+        }
+        *(uint4*)((char*)d.dst.ptr + ((size_t)pix[u] * d.dst.Cp + d.dst.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(gv);
+    }
+}
+
 extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
     if (!d || (d->dtype != MFC_F32 && d->dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
     const int E = d->dtype == MFC_BF16 ? 8 : 4;
@@ -403,6 +506,13 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
     const long total = (long)d->N * d->dst.H * d->dst.W * Cg;
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
+    if (d->dst.H == d->g.H && d->dst.W == d->g.W) {
+        const int b4 = (int)((total + 1023) / 1024);
+        if (d->dtype == MFC_BF16) hipLaunchKernelGGL(mask_add_same_kernel<bf16_t>, dim3(b4), dim3(256), 0, st, *d, total, Cg);
+        else hipLaunchKernelGGL(mask_add_same_kernel<float>, dim3(b4), dim3(256), 0, st, *d, total, Cg);
+        MFC_CHECK_LAUNCH();
+        return MFC_OK;
+    }
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(mask_add_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
     else hipLaunchKernelGGL(mask_add_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
     MFC_CHECK_LAUNCH();
