@@ -243,7 +243,12 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_fast_kernel(Wgrad
     float* coefs = (float*)(smem + p.off_coef);  // [G][2][gx*8] scale / shift of this block's input channels
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int y = blockIdx.y;
+    // 1-D grid, weight block fastest, XCD-contiguous: the Y workgroups that walk the SAME pixel tiles run on one XCD at the
+    // same time, so their re-reads of the dy / x tiles hit that XCD's L2 (PMC: 8-10x over-fetch from HBM otherwise)
+    const int Ytot = p.TA * p.co_blocks * p.ci_blocks;
+    const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    int y = Lb % Ytot;
+    const int bsplit = Lb / Ytot;
     const int ib = y % p.ci_blocks; y /= p.ci_blocks;
     const int cb = y % p.co_blocks; const int a = y / p.co_blocks;
     const int wc = wave % p.gc, wi = (wave / p.gc) % p.gi, wk = wave / (p.gc * p.gi);
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_fast_kernel(Wgrad
     typedef __attribute__((address_space(3))) s16x4 lds_s4;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     int it = 0;
-    int tile = blockIdx.x;
+    int tile = bsplit;
     if (tile < p.ntiles) { load_tile(tile); store_tile(smem); }
     __syncthreads();
     for (; tile < p.ntiles; tile += p.splits, ++it) {
@@ -479,7 +484,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* wbase = smem + wave * p.wave_bytes;
-    int y = blockIdx.y;
+    // 1-D grid, weight block fastest, XCD-contiguous (see conv_wgrad_fast_kernel): co-scheduled re-reads hit the XCD's L2
+    const int Ytot = p.TA * p.co_blocks * p.ci_blocks;
+    const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    int y = Lb % Ytot;
+    const int bsplit = Lb / Ytot;
     const int ib = y % p.ci_blocks; y /= p.ci_blocks;
     const int cb = y % p.co_blocks; const int a = y / p.co_blocks;
     const int co0 = cb * WCO * 16, ci0 = ib * WCI * 16;
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     __syncthreads();                               // tables + coefficients visible
     const int stride = p.splits * 4;
-    int tile = blockIdx.x * 4 + wave;
+    int tile = bsplit * 4 + wave;
     if (tile < p.ntiles) { load_tile(tile); store_tile(wbase); }
     const int pr0 = 8 * (lane >> 4) + ((lane & 15) >> 2);
     const int csub = (lane & 3) * 8;
@@ -715,7 +724,7 @@ static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st)
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
         mfc_prof_before(st, 1 * 16 + 8 + (TB == 1 ? 0 : TB == 3 ? 1 : 2), flops, bytes);
     }
-    hipLaunchKernelGGL((conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>), dim3(f.splits, Y), dim3(256), lds, st, f);
+    hipLaunchKernelGGL((conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>), dim3(f.splits * Y), dim3(256), lds, st, f);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -795,7 +804,7 @@ static int wgrad_wave_launch(const WgradW& f, size_t lds, int Y, hipStream_t st)
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
         mfc_prof_before(st, 1 * 16 + 8 + (TB == 3 ? 1 : 2), flops, bytes);
     }
-    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TB, WCO, WCI, XP>), dim3(f.splits, Y), dim3(256), lds, st, f);
+    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TB, WCO, WCI, XP>), dim3(f.splits * Y), dim3(256), lds, st, f);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
