@@ -470,10 +470,10 @@ struct WgradW {
     int TA, TB, dh0, dw0, s, in_relu, ipg, G;
     int TH, TW, tilesY, tilesX, ntiles, splits;     // sub-tile (TH*TW <= 32)
     int Co16, Ci16, co_blocks, ci_blocks;
-    int gd, gx, PW, pitch_d, pitch_x, off_x, buf_bytes, wave_bytes, off_tab, off_coef;
+    int gd, gx, PW, PHX, pitch_d, pitch_x, off_x, buf_bytes, wave_bytes, off_tab, off_coef;
 };
 
-template <int TB, int WCO, int WCI, int XP>
+template <int TAA, int TB, int WCO, int WCI, int XP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
     typedef bf16_t T;
     constexpr int E = 8;
@@ -485,17 +485,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* wbase = smem + wave * p.wave_bytes;
     // 1-D grid, weight block fastest, XCD-contiguous (see conv_wgrad_fast_kernel): co-scheduled re-reads hit the XCD's L2
-    const int Ytot = p.TA * p.co_blocks * p.ci_blocks;
+    const int Ytot = (p.TA / TAA) * p.co_blocks * p.ci_blocks;
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
     int y = Lb % Ytot;
     const int bsplit = Lb / Ytot;
     const int ib = y % p.ci_blocks; y /= p.ci_blocks;
-    const int cb = y % p.co_blocks; const int a = y / p.co_blocks;
+    const int cb = y % p.co_blocks; const int a = (y / p.co_blocks) * TAA;     // first tap row of this workgroup
     const int co0 = cb * WCO * 16, ci0 = ib * WCI * 16;
 
     if (tid < 32) {
         int ty = tid / p.TW, tx = tid - ty * p.TW;
-        xoff[tid] = (tid < p.TH * p.TW) ? (ty * p.PW + tx * p.s) * p.pitch_x : 0;
+        xoff[tid] = (tid < p.TH * p.TW) ? (ty * p.s * p.PW + tx * p.s) * p.pitch_x : 0;
     }
     if (p.in_coef) {
         const int nch = p.gx * 8;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
         }
     }
     // per-lane staging pieces: idx = lane + i*64 -> (pixel, granule); packed gi | px<<4 | ty<<12, bit 30 = zero row/granule
-    const int npx = p.TH * p.PW;
+    const int npx = p.PHX * p.PW;               // staged input rows: ((TH-1)*s + TAA) x PW
     int dpk[DP], xpk[XP];
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
@@ -522,9 +522,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
         xpk[i] = (pix < npx) ? (gi | (px << 4) | (ty << 12) | (((ci0 + gi * E) >= p.Cin_p) ? (1 << 30) : 0)) : -1;
     }
 
-    f32x4 acc[TB][WCO][WCI];
+    f32x4 acc[TAA * TB][WCO][WCI];
 #pragma unroll
-    for (int b = 0; b < TB; ++b)
+    for (int b = 0; b < TAA * TB; ++b)
 #pragma unroll
         for (int i = 0; i < WCO; ++i)
 #pragma unroll
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
         const int ihb = i0 * p.s + p.dh0 + a, iwb = j0 * p.s + p.dw0;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const int ih = ihb + ((xpk[i] >> 12) & 0xff) * p.s, iw = iwb + ((xpk[i] >> 4) & 0xff);
+            const int ih = ihb + ((xpk[i] >> 12) & 0xff), iw = iwb + ((xpk[i] >> 4) & 0xff);
             const bool inr = xpk[i] >= 0 && !(xpk[i] & (1 << 30)) && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
             const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
             const int gic = ((ci0 + (xpk[i] & 15) * E) < p.Cin_p) ? (xpk[i] & 15) : 0;
@@ -619,12 +619,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
             af[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
 #pragma unroll
-        for (int b = 0; b < TB; ++b) {
+        for (int b = 0; b < TAA * TB; ++b) {
+            const int toff = ((b / TB) * p.PW + (b % TB)) * p.pitch_x;      // tap (row b/TB, column b%TB)
             bf16x8 bfr[WCI];
 #pragma unroll
             for (int j = 0; j < WCI; ++j) {
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Xs + xo0 + b * p.pitch_x + j * 32));
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Xs + xo1 + b * p.pitch_x + j * 32));
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Xs + xo0 + toff + j * 32));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(Xs + xo1 + toff + j * 32));
                 bfr[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
         if (nxt < p.ntiles) store_tile(wbase + ((it + 1) & 1) * p.buf_bytes);
     }
     // ---- tree-reduce the four waves' accumulators through LDS, then one wave issues the atomics ----
-    constexpr int NTW = TB * WCO * WCI;
+    constexpr int NTW = TAA * TB * WCO * WCI;
     bool flusher = true;
     for (int half = 2; half >= 1; half >>= 1) {
         __syncthreads();
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
         if (dump) {
             int t = 0;
 #pragma unroll
-            for (int b = 0; b < TB; ++b)
+            for (int b = 0; b < TAA * TB; ++b)
 #pragma unroll
                 for (int i = 0; i < WCO; ++i)
 #pragma unroll
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
         if (take) {
             int t = 0;
 #pragma unroll
-            for (int b = 0; b < TB; ++b)
+            for (int b = 0; b < TAA * TB; ++b)
 #pragma unroll
                 for (int i = 0; i < WCO; ++i)
 #pragma unroll
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
     }
     if (flusher) {
 #pragma unroll
-        for (int b = 0; b < TB; ++b)
+        for (int b = 0; b < TAA * TB; ++b)
 #pragma unroll
             for (int i = 0; i < WCO; ++i)
 #pragma unroll
@@ -792,11 +793,11 @@ static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st) {
     return MFC_ERR_UNSUPPORTED;
 }
 
-template <int TB, int WCO, int WCI, int XP>
+template <int TAA, int TB, int WCO, int WCI, int XP>
 static int wgrad_wave_launch(const WgradW& f, size_t lds, int Y, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<TB, WCO, WCI, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on) {
@@ -804,7 +805,7 @@ static int wgrad_wave_launch(const WgradW& f, size_t lds, int Y, hipStream_t st)
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
         mfc_prof_before(st, 1 * 16 + 8 + (TB == 3 ? 1 : 2), flops, bytes);
     }
-    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TB, WCO, WCI, XP>), dim3(f.splits * Y), dim3(256), lds, st, f);
+    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP>), dim3(f.splits * Y), dim3(256), lds, st, f);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -838,27 +839,35 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st) {
     int WCO, WCI;
     if (d->TB == 11) { WCO = 1; WCI = ci_t >= 2 ? 2 : 1; }
     else { WCO = ceil_div(co_t, ceil_div(co_t, 3)); WCI = ceil_div(ci_t, ceil_div(ci_t, 3)); }
+    // all-taps mode (3x3, 32x32-channel blocks): one workgroup accumulates all 9 taps, so the input rows are staged once
+    // for the three tap rows instead of once per row (3x fewer staging instructions per MFMA)
+    const bool alltaps = d->TB == 3 && d->TA == 3 && co_t % 2 == 0 && ci_t % 2 == 0 && g_wgrad_ksplit != 3 &&
+                         ceil_div(((f.TH - 1) * f.s + 3) * ((f.TW - 1) * f.s + 3) * 4, 64) <= 4;     // staging must fit 4 pieces/lane
+    if (alltaps) { WCO = 2; WCI = 2; }
+    const int TAA = alltaps ? 3 : 1;
     f.co_blocks = ceil_div(co_t, WCO); f.ci_blocks = ceil_div(ci_t, WCI);
     f.gd = WCO * 2; f.gx = WCI * 2;
     f.PW = (f.TW - 1) * f.s + f.TB;
+    f.PHX = (f.TH - 1) * f.s + TAA;
     f.pitch_d = f.gd * 16 + 16; f.pitch_x = f.gx * 16 + 16;
-    const int nxp = ceil_div(f.TH * f.PW * f.gx, 64);
+    const int nxp = ceil_div(f.PHX * f.PW * f.gx, 64);
     if (ceil_div(32 * f.gd, 64) > 3 || nxp > 7 || f.PW > 255) return MFC_ERR_UNSUPPORTED;
-    const size_t ds = ((size_t)32 * f.pitch_d + 15) & ~(size_t)15, xs = ((size_t)f.TH * f.PW * f.pitch_x + 15) & ~(size_t)15;
+    const size_t ds = ((size_t)32 * f.pitch_d + 15) & ~(size_t)15, xs = ((size_t)f.PHX * f.PW * f.pitch_x + 15) & ~(size_t)15;
     f.off_x = (int)ds; f.buf_bytes = (int)(ds + xs); f.wave_bytes = 2 * f.buf_bytes;
     size_t stage = (size_t)4 * f.wave_bytes;
-    const size_t need = (size_t)2 * d->TB * WCO * WCI * 1024;            // tree reduction scratch (2 dumping waves)
+    const size_t need = (size_t)2 * TAA * d->TB * WCO * WCI * 1024;      // tree reduction scratch (2 dumping waves)
     if (stage < need) stage = need;
     f.off_tab = (int)stage; f.off_coef = f.off_tab + 32 * 4;
     const size_t lds = (size_t)f.off_coef + (d->in_coef ? (size_t)f.G * 2 * f.gx * 8 * 4 : 0);
     if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
-    const int Y = f.TA * f.co_blocks * f.ci_blocks;
+    const int Y = (f.TA / TAA) * f.co_blocks * f.ci_blocks;
     int S = d->splits;
     if (S <= 0) S = ceil_div(512, Y);
     if (S * 4 > f.ntiles) S = ceil_div(f.ntiles, 4);
     if (S < 1) S = 1;
     f.splits = S;
-#define WGW(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return nxp <= 4 ? wgrad_wave_launch<tb, a_, b_, 4>(f, lds, Y, st) : wgrad_wave_launch<tb, a_, b_, 7>(f, lds, Y, st);
+    if (alltaps) return wgrad_wave_launch<3, 3, 2, 2, 4>(f, lds, Y, st);
+#define WGW(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return nxp <= 4 ? wgrad_wave_launch<1, tb, a_, b_, 4>(f, lds, Y, st) : wgrad_wave_launch<1, tb, a_, b_, 7>(f, lds, Y, st);
     WGW(3, 3, 3) WGW(3, 3, 2) WGW(3, 3, 1) WGW(3, 2, 3) WGW(3, 2, 2) WGW(3, 2, 1) WGW(3, 1, 3) WGW(3, 1, 2) WGW(3, 1, 1)
     WGW(11, 1, 2) WGW(11, 1, 1)
 #undef WGW
