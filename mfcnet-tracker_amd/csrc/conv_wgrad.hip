@@ -811,10 +811,12 @@ static int wgrad_wave_launch(const WgradW& f, size_t lds, int Y, hipStream_t st)
     return MFC_OK;
 }
 
-static void choose_subtile(int Hl, int Wl, int& TH, int& TW) {
-    double best = -1; int bh = 2, bw = 16;
+// max_patch > 0: the (TH + 2) x (TW + 2) halo patch must not exceed it (all-taps staging budget)
+static void choose_subtile(int Hl, int Wl, int& TH, int& TW, int max_patch = 0) {
+    double best = -1; int bh = 0, bw = 0;
     for (int tw = 1; tw <= 32 && tw <= Wl; ++tw) {
         int th = 32 / tw; if (th > Hl) th = Hl; if (th < 1) continue;
+        if (max_patch > 0 && (th + 2) * (tw + 2) > max_patch) continue;
         double tiles = (double)ceil_div(Hl, th) * ceil_div(Wl, tw);
         double eff = (double)Hl * Wl / (tiles * 32.0);
         double score = eff + ((tw % 8 == 0) ? 0.01 : 0.0) + 0.02 * (double)tw / (tw + 2.0);   // wide rows: less halo
@@ -831,18 +833,20 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st) {
     f.N = d->N; f.Hin = d->Hin; f.Win = d->Win; f.Cin_p = d->Cin_p; f.Hout = d->Hout; f.Wout = d->Wout; f.Cout_p = d->Cout_p;
     f.TA = d->TA; f.TB = d->TB; f.dh0 = d->dh0; f.dw0 = d->dw0; f.s = d->in_stride; f.in_relu = d->in_relu; f.ipg = d->images_per_group;
     f.G = d->N / d->images_per_group;
-    choose_subtile(d->Hout, d->Wout, f.TH, f.TW);
-    f.tilesY = ceil_div(d->Hout, f.TH); f.tilesX = ceil_div(d->Wout, f.TW);
-    f.ntiles = f.N * f.tilesY * f.tilesX;
     f.Co16 = ceil_div(d->Cout, 16) * 16; f.Ci16 = ceil_div(d->Cin, 16) * 16;
     const int co_t = f.Co16 / 16, ci_t = f.Ci16 / 16;
+    const bool want_all = d->TB == 3 && d->TA == 3 && d->in_stride == 1 && co_t % 2 == 0 && ci_t % 2 == 0 && g_wgrad_ksplit != 3;
+    f.TH = 0; f.TW = 0;
+    if (want_all) choose_subtile(d->Hout, d->Wout, f.TH, f.TW, 64);     // 64 patch pixels x 4 granules = 4 pieces per lane
+    if (f.TH == 0) choose_subtile(d->Hout, d->Wout, f.TH, f.TW);
+    f.tilesY = ceil_div(d->Hout, f.TH); f.tilesX = ceil_div(d->Wout, f.TW);
+    f.ntiles = f.N * f.tilesY * f.tilesX;
     int WCO, WCI;
     if (d->TB == 11) { WCO = 1; WCI = ci_t >= 2 ? 2 : 1; }
     else { WCO = ceil_div(co_t, ceil_div(co_t, 3)); WCI = ceil_div(ci_t, ceil_div(ci_t, 3)); }
     // all-taps mode (3x3, 32x32-channel blocks): one workgroup accumulates all 9 taps, so the input rows are staged once
     // for the three tap rows instead of once per row (3x fewer staging instructions per MFMA)
-    const bool alltaps = d->TB == 3 && d->TA == 3 && co_t % 2 == 0 && ci_t % 2 == 0 && g_wgrad_ksplit != 3 &&
-                         ceil_div(((f.TH - 1) * f.s + 3) * ((f.TW - 1) * f.s + 3) * 4, 64) <= 4;     // staging must fit 4 pieces/lane
+    const bool alltaps = want_all && ceil_div(((f.TH - 1) * f.s + 3) * ((f.TW - 1) * f.s + 3) * 4, 64) <= 4;     // staging must fit 4 pieces/lane
     if (alltaps) { WCO = 2; WCI = 2; }
     const int TAA = alltaps ? 3 : 1;
     f.co_blocks = ceil_div(co_t, WCO); f.ci_blocks = ceil_div(ci_t, WCI);
@@ -862,7 +866,7 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st) {
     if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
     const int Y = (f.TA / TAA) * f.co_blocks * f.ci_blocks;
     int S = d->splits;
-    if (S <= 0) S = ceil_div(512, Y);
+    if (S <= 0) S = ceil_div(320, Y);          // ~1.25 workgroups per CU in total: every extra workgroup is one more atomic flush (measured sweep)
     if (S * 4 > f.ntiles) S = ceil_div(f.ntiles, 4);
     if (S < 1) S = 1;
     f.splits = S;
