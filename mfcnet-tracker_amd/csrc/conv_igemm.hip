@@ -36,6 +36,7 @@ struct ConvK {
     int Yblocks, nunits, per_block;     // units = cout blocks (slow) x tiles (fast); units per workgroup
     int nslots, npieces, stage_bytes;   // weight slots per stage, 1-KiB DMA pieces per stage, bytes of one stage image
     int off_w0, off_w1, off_ktab, off_red;   // LDS offsets (bytes)
+    int ablate;                              // tuning only: 1 skip weight DMA, 2 skip patch staging, 4 skip output stores, 8 skip MFMAs
 };
 
 template <int CTRL> __device__ inline float dpp_add(float v) {
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         if (a2 == p.nstg) { a2 = 0; ++c2; if (c2 == p.nchunks) { c2 = 0; ++tl2; uc2 = uc_next(uc); } }
         const bool nxt = (g + 1 < total);
         const bool newpatch = nxt && (a2 == 0) && (p.nchunks > 1 || tl2 != tl);
-        if (nxt) dma_w(uc2, c2, a2, smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
-        if (newpatch) load_patch(uc2, c2);
+        if (nxt && !(p.ablate & 1)) dma_w(uc2, c2, a2, smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
+        if (newpatch && !(p.ablate & 2)) load_patch(uc2, c2);
         if (red_pending) stats_flush();
 
         // ---------------- compute stage (tl, c, a) ----------------
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                 };
                 ldx(xa, 0); ldw(wa, 0);
                 int ks = 0;
+                if (p.ablate & 8) ks = nk;
                 for (; ks + 2 <= nk; ks += 2) {
                     ldx(xb, ks + 1); ldw(wb, ks + 1);
                     mm(wa, xa);
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (co + r < p.Cout) v[r] += p.bias[co + r];
                     }
-                    if (valid && co < p.Cout_p) {
+                    if (valid && co < p.Cout_p && !(p.ablate & 4)) {
                         T* o = orow + co;
                         if (p.accumulate) {
 #pragma unroll
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         // ---------------- hand over to the next stage ----------------
         if (newpatch) {
             __syncthreads();           // every wave has finished reading the current patch
-            store_patch();
+            if (!(p.ablate & 2)) store_patch();
         }
         dma_wait();                    // the weight DMA of stage g+1 has landed (this wave's pieces) ...
         __syncthreads();               // ... and everybody's
@@ -385,6 +387,12 @@ static void choose_tile(int Hl, int Wl, int cap, int& TH, int& TW, double& eff_o
 static int g_conv_num_cu = 256;
 static int g_conv_force_mt = 0;      // tuning: mfc_set_flag(2, 2|4)
 int mfc_conv_set_force_mt(int v) { g_conv_force_mt = v; return 0; }
+static int g_conv_lds_kb = 80;       // LDS budget per workgroup (80 KiB -> 2 workgroups per CU); tuning: mfc_set_flag(6, kb)
+int mfc_conv_set_lds_kb(int v) { g_conv_lds_kb = v > 0 ? v : 80; return 0; }
+static int g_conv_ablate = 0;
+int mfc_conv_set_ablate(int v) { g_conv_ablate = v; return 0; }
+static int g_conv_grid = 512;        // persistent workgroups per launch (2 per CU); tuning: mfc_set_flag(4, n)
+int mfc_conv_set_grid(int v) { g_conv_grid = v > 0 ? v : 512; return 0; }
 
 static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid) {
     if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
@@ -457,7 +465,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
                 // register budget (no spills: a spill in the prefetch path serialises it): wide N tiles keep fewer
                 // pixel tiles / prefetch pieces per thread
                 int pm_max = mt == 4 ? (NT == 6 ? 0 : NT == 4 ? 3 : 6) : (NT == 6 ? 4 : 10);
-                if (l > 80 * 1024 || pm > pm_max || t.nslots > 256) continue;
+                if (l > (size_t)g_conv_lds_kb * 1024 || pm > pm_max || t.nslots > 256) continue;
                 const double mf = (E == 8 ? t.nslots / 4 : t.nslots) * mt * NT;      // MFMAs per wave per stage
                 const double score = eff * fill * ((double)real / t.nslots) * (mf / (mf + 40.0)) * (mt == 4 ? 1.0 : 0.93);
                 if (score > best_score) { best_score = score; bk = t; bMT = mt; bPM = pm; blds = l; }
@@ -469,7 +477,8 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     if (!ok) return MFC_ERR_UNSUPPORTED;
     k.ntiles = k.N * k.tilesY * k.tilesX;
     k.nunits = k.ntiles * k.Yblocks;
-    grid = 2 * g_conv_num_cu;
+    k.ablate = g_conv_ablate;
+    grid = g_conv_grid;
     if (grid > k.nunits) grid = k.nunits;
     k.per_block = ceil_div(k.nunits, grid);
     grid = ceil_div(k.nunits, k.per_block);

@@ -17,10 +17,16 @@
 static int g_wgrad_use_tr = 1;
 static int g_wgrad_ksplit = 0;      // tuning: mfc_set_flag(3, 1) forces gc = gi = 1 (every wave holds all tiles, 4-way K split)
 int mfc_conv_set_force_mt(int v);
+int mfc_conv_set_grid(int v);
+int mfc_conv_set_ablate(int v);
+int mfc_conv_set_lds_kb(int v);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
     if (id == 3) { g_wgrad_ksplit = value; return 0; }
+    if (id == 4) return mfc_conv_set_grid(value);
+    if (id == 5) return mfc_conv_set_ablate(value);
+    if (id == 6) return mfc_conv_set_lds_kb(value);
     return MFC_ERR_INVALID_ARG;
 }
 
@@ -866,7 +872,7 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st) {
     if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
     const int Y = (f.TA / TAA) * f.co_blocks * f.ci_blocks;
     int S = d->splits;
-    if (S <= 0) S = ceil_div(320, Y);          // ~1.25 workgroups per CU in total: every extra workgroup is one more atomic flush (measured sweep)
+    if (S <= 0) S = ceil_div(d->TB == 11 ? 512 : 320, Y);   // ~1.25 workgroups per CU: every extra workgroup is one more atomic flush (measured sweep)
     if (S * 4 > f.ntiles) S = ceil_div(f.ntiles, 4);
     if (S < 1) S = 1;
     f.splits = S;

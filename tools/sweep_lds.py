@@ -1,0 +1,21 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
+import torch
+from mfcnet_amd import _lib as L, ops
+from bench_conv import timeit
+for (N, Cin, Cout, k, s, H, W) in [(24, 32, 32, 3, 1, 120, 160), (24, 48, 48, 3, 1, 120, 160), (24, 64, 64, 3, 1, 60, 80), (24, 96, 96, 3, 1, 60, 80), (24, 192, 192, 3, 1, 30, 40), (24, 384, 384, 3, 1, 15, 20), (24, 720, 720, 1, 1, 120, 160)]:
+    dt = torch.bfloat16; pad = k // 2
+    x = torch.randn(N, H, W, ops.rup(Cin, 8), device="cuda").to(dt)
+    w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
+    out = torch.zeros(N, H, W, ops.rup(Cout, 8), dtype=dt, device="cuda")
+    flops = 2.0 * N * H * W * Cout * Cin * k * k
+    line = f"{(N,Cin,Cout,k,s,H,W)}"
+    for kb, G in ((80, 512), (110, 256), (110, 512), (156, 256)):
+        L.lib.mfc_set_flag(6, kb); L.lib.mfc_set_flag(4, G)
+        d = L.ConvDesc(x.data_ptr(), 0, out.data_ptr(), 0, 0, 0, ops.dt_of(x), N, H, W, x.shape[3], Cin, H, W, out.shape[3], Cout, H, W, k, k, -pad, -pad, s, 1, 1, 0, 0, 0, N, 0, 0, 0)
+        wp = ops.pack_weight(w, d, "fwd"); d.wp = wp.data_ptr()
+        lay = L.conv_layout(d)
+        t = timeit(lambda: L.call(L.lib.mfc_conv2d_fwd, d))
+        line += f" | {kb}K/g{G}: NT{lay.NT16//16} MT{lay.MT} KG{lay.KG} TAS{lay.TAS} {lay.lds_bytes//1024}K {t*1e6:6.1f}us {flops/t/1e12:4.0f}TF"
+    print(line, flush=True)
