@@ -319,6 +319,9 @@ typedef struct {
 } mfc_op;
 /* runs ops[0..n); returns 0 or (-(1000*index) + status) of the first failing record */
 int mfc_program_run(const mfc_op* ops, int32_t n, void* stream);
+/* tuning aid: the same, with a HIP event between records (each record launched `reps` times back to back);
+ * synchronises the stream and returns the stream time per record and repetition in ms_out[n] */
+int mfc_program_profile(const mfc_op* ops, int32_t n, int32_t reps, float* ms_out, void* stream);
 /* In-process kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
  * While enabled, every conv forward/dgrad and wgrad launch is bracketed by two events; mfc_prof_collect
  * synchronises and sums elapsed time, launches and algorithmic FLOPs per bucket.

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     const int u0 = Lb * p.per_block;
     const int nun = min(p.per_block, p.nunits - u0);
     if (nun <= 0) return;
+    if (p.ablate & 16) return;
     const int SPT = p.nchunks * p.nstg;
     const int total = nun * SPT;
     const int npix = p.PH * p.PW;
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     dma_wait();
     __syncthreads();
 
+    if (p.ablate & 32) return;
     int tl = 0, c = 0, a = 0;          // current stage coordinates (a = tap-row group)
     for (int g = 0; g < total; ++g) {
         int tl2 = tl, c2 = c, a2 = a + 1;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         }
 
         // ---------------- tile epilogue ----------------
-        if (c == p.nchunks - 1 && a == p.nstg - 1) {
+        if (c == p.nchunks - 1 && a == p.nstg - 1 && !(p.ablate & 64)) {
             const int n = uc.n, i0 = uc.tyi * p.TH, j0 = uc.txi * p.TW, yb = uc.yb;
             const int n0 = yb * NT16;
 #pragma unroll
@@ -331,8 +333,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                     if (valid && co < p.Cout_p && !(p.ablate & 4)) {
                         T* o = orow + co;
                         if (p.accumulate) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += ld_elem<T>(o + r);
+                            if constexpr (BF) {
+                                const uint2 ov = *(const uint2*)o;
+                                v[0] += __uint_as_float(ov.x << 16); v[1] += __uint_as_float(ov.x & 0xffff0000u);
+                                v[2] += __uint_as_float(ov.y << 16); v[3] += __uint_as_float(ov.y & 0xffff0000u);
+                            } else {
+                                const float4 ov = *(const float4*)o;
+                                v[0] += ov.x; v[1] += ov.y; v[2] += ov.z; v[3] += ov.w;
+                            }
                         }
                         if constexpr (BF) {
                             *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));

@@ -88,11 +88,11 @@ __device__ inline void load_gran_f(const mfc_view& v, int n, int h, int w, int c
 template <typename T>
 __global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, long total, int Cg) {
     constexpr int E = Gran<T>::E;
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % Cg); long pix = idx / Cg;
-    const int w = (int)(pix % d.out.W); pix /= d.out.W;
-    const int h = (int)(pix % d.out.H); const int n = (int)(pix / d.out.H);
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // (host guarantees total < 2^31: 32-bit index arithmetic)
+    if (idx >= (unsigned)total) return;
+    const int g = (int)(idx % (unsigned)Cg); unsigned pix = idx / (unsigned)Cg;
+    const int w = (int)(pix % (unsigned)d.out.W); pix /= (unsigned)d.out.W;
+    const int h = (int)(pix % (unsigned)d.out.H); const int n = (int)(pix / (unsigned)d.out.H);
     const int grp = n / d.images_per_group;
     float acc[E];
 #pragma unroll
@@ -135,21 +135,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, long total, int Cg) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 2;
-    const long base = ((long)blockIdx.x * 256) * U + threadIdx.x;
-    const long ppg = (long)d.images_per_group * d.out.H * d.out.W;
-    uint4 r[U][4]; long pix[U]; int gq[U];
+    const unsigned base = (blockIdx.x * 256u) * U + threadIdx.x;
+    const unsigned ppg = (unsigned)d.images_per_group * d.out.H * d.out.W;
+    uint4 r[U][4]; unsigned pix[U]; int gq[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        long idx = base + (long)u * 256;
-        if (idx >= total) idx = total - 1;
-        gq[u] = (int)(idx % Cg); pix[u] = idx / Cg;
+        unsigned idx = base + u * 256u;
+        if (idx >= (unsigned)total) idx = (unsigned)total - 1;
+        pix[u] = idx / (unsigned)Cg; gq[u] = (int)(idx - pix[u] * (unsigned)Cg);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < d.nsrc) r[u][k] = *(const uint4*)((const char*)d.src[k].ptr + ((size_t)pix[u] * d.src[k].Cp + d.src[k].c_off + gq[u] * E) * sizeof(T));
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if (base + (long)u * 256 >= total) break;
+        if (base + u * 256u >= (unsigned)total) break;
         const int grp = (int)(pix[u] / ppg);
         float acc[E];
 #pragma unroll
@@ -188,6 +188,7 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
         if (!view_ok(d->src[k], E) || d->src[k].c_off + d->C > d->src[k].Cp) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     const long total = (long)d->N * d->out.H * d->out.W * Cg;
+    if (total >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;      // kernels index granules with 32 bits
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     bool same = true;
@@ -265,20 +266,25 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
             }
         }
     }
+    // tree reduction over the pixel rows of the block (all threads take part), then one atomic per (stat, channel)
 #pragma unroll
-    for (int e = 0; e < E; ++e) { red[(threadIdx.x * E + e) * 2] = s1[e]; red[(threadIdx.x * E + e) * 2 + 1] = s2[e]; }
+    for (int e = 0; e < E; ++e) { red[(e * 2 + 0) * 256 + threadIdx.x] = s1[e]; red[(e * 2 + 1) * 256 + threadIdx.x] = s2[e]; }
     __syncthreads();
-    if (prow == 0) {
+    for (int n = PPI; n > 1;) {
+        const int half = (n + 1) >> 1;
+        if (prow + half < n) {
+#pragma unroll
+            for (int k = 0; k < 2 * E; ++k) red[k * 256 + threadIdx.x] += red[k * 256 + threadIdx.x + half * Cg];
+        }
+        n = half;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 2 * E * Cg; i += blockDim.x) {
+        const int k = i / Cg, g2 = i - k * Cg;        // k = e*2 + stat
         const int rep = blockIdx.x % MFC_R;
         const int G = gridDim.y;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            float a = 0.f, b = 0.f;
-            for (int q = 0; q < PPI; ++q) { a += red[((q * Cg + gi) * E + e) * 2]; b += red[((q * Cg + gi) * E + e) * 2 + 1]; }
-            const int c = d.y.c_off + gi * E + e;
-            atomicAdd(d.bstats + (((size_t)rep * G + grp) * 2 + 0) * d.y.Cp + c, a);
-            atomicAdd(d.bstats + (((size_t)rep * G + grp) * 2 + 1) * d.y.Cp + c, b);
-        }
+        const int c = d.y.c_off + g2 * E + (k >> 1);
+        atomicAdd(d.bstats + (((size_t)rep * G + grp) * 2 + (k & 1)) * d.y.Cp + c, red[k * 256 + g2]);
     }
 }
 
@@ -301,7 +307,7 @@ extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
     const int PPI = 256 / Cg;
     const int G = d->N / d->images_per_group;
     const long ppg = (long)d->images_per_group * d->y.H * d->y.W;
-    long want = ppg / 192 + 1; if (want > 2048 / G + 1) want = 2048 / G + 1;       // blocks per group (~2048 in total)
+    long want = ppg / (8L * PPI) + 1; if (want > 1024 / G + 1) want = 1024 / G + 1;   // blocks per group (~1024 in total, >= 8 pixels per thread)
     int ppb = (int)((ppg + want - 1) / want);
     ppb = ((ppb + PPI - 1) / PPI) * PPI;
     const int bx = (int)((ppg + ppb - 1) / ppb);
@@ -349,21 +355,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long total, int Cg) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 4;                                   // granules in flight per thread
-    const long base = ((long)blockIdx.x * 256) * U + threadIdx.x;
-    const long ppg = (long)d.images_per_group * d.y.H * d.y.W;
-    uint4 yr[U], gr[U], mr[U]; long pix[U]; int gq[U];
+    const unsigned base = (blockIdx.x * 256u) * U + threadIdx.x;      // (host guarantees total < 2^31)
+    const unsigned ppg = (unsigned)d.images_per_group * d.y.H * d.y.W;
+    uint4 yr[U], gr[U], mr[U]; unsigned pix[U]; int gq[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        long idx = base + (long)u * 256;
-        if (idx >= total) idx = total - 1;                 // clamp: branch-free loads, masked at the store
-        gq[u] = (int)(idx % Cg); pix[u] = idx / Cg;
+        unsigned idx = base + u * 256u;
+        if (idx >= (unsigned)total) idx = (unsigned)total - 1;   // clamp: branch-free loads, masked at the store
+        pix[u] = idx / (unsigned)Cg; gq[u] = (int)(idx - pix[u] * (unsigned)Cg);
         yr[u] = ld_lin<T>(d.y, pix[u], d.y.c_off + gq[u] * E);
         gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
         if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if (base + (long)u * 256 >= total) break;
+        if (base + u * 256u >= (unsigned)total) break;
         const int grp = (int)(pix[u] / ppg);
         const int c = d.y.c_off + gq[u] * E;
         const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + c;
@@ -385,6 +391,7 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
     if (!d->bcoef || !view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     const long total = (long)d->N * d->y.H * d->y.W * Cg;
+    if (total >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;      // kernels index granules with 32 bits
     const int blocks = (int)((total + 1023) / 1024);
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
@@ -403,44 +410,64 @@ __device__ inline void adj_range(int s, int in_size, int out_size, int& lo, int&
     if (hi > out_size - 1) hi = out_size - 1;
 }
 
+// adjoint of the bilinear up-sampling (gather form): S = 2^LS adjacent lanes share one low-resolution granule and split
+// the candidate high-resolution rows between them (a x8 fuse-path adjoint has ~18x18 candidates per output granule);
+// the separable column weights are computed once per 8-column chunk; partial sums meet through lane shuffles.
 template <typename T>
-__global__ __launch_bounds__(256) void mask_add_kernel(mfc_maskadd_desc d, long total, int Cg) {
+__global__ __launch_bounds__(256) void mask_add_kernel(mfc_maskadd_desc d, long npixout, int Cg, int LS, int PB) {
     constexpr int E = Gran<T>::E;
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % Cg); long pix = idx / Cg;
-    const int w = (int)(pix % d.dst.W); pix /= d.dst.W;
-    const int h = (int)(pix % d.dst.H); const int n = (int)(pix / d.dst.H);
+    __shared__ float red[256 * E];
+    // workgroup = PB output pixels x S column lanes x Cg granules (granule fastest: a row read touches S*Cg contiguous granules)
+    const unsigned S = 1u << LS;
+    const unsigned tid = threadIdx.x;
+    const int g = (int)(tid % (unsigned)Cg);
+    const unsigned t2 = tid / (unsigned)Cg, j = t2 & (S - 1);
+    unsigned pix = blockIdx.x * (unsigned)PB + (t2 >> LS);
+    const bool live = (t2 >> LS) < (unsigned)PB && pix < (unsigned)npixout;
+    if (!live) pix = (unsigned)npixout - 1;
+    const int w = (int)(pix % (unsigned)d.dst.W); pix /= (unsigned)d.dst.W;
+    const int h = (int)(pix % (unsigned)d.dst.H); const int n = (int)(pix / (unsigned)d.dst.H);
     float acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
-    if (d.dst.H == d.g.H && d.dst.W == d.g.W) {
-        load_gran_f<T>(d.g, n, h, w, d.g.c_off + g * E, acc);
-        if (d.mask_mode == 1) {
-            float m[E];
-            load_gran_f<T>(d.mask, n, h, w, d.mask.c_off + g * E, m);
+    int hlo, hhi, wlo, whi;
+    adj_range(h, d.dst.H, d.g.H, hlo, hhi);
+    adj_range(w, d.dst.W, d.g.W, wlo, whi);
+    // the S lanes of an output granule take adjacent candidate COLUMNS (with the granule index fastest, a wave touches
+    // S*Cg contiguous granules per row); the row weights are computed once per 8-row chunk
+    for (int hh0 = hlo; hh0 <= hhi; hh0 += 8) {
+        float wrow[8];
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = m[e] > 0.f ? acc[e] : 0.f;
-        }
-    } else {
-        int hlo, hhi, wlo, whi;
-        adj_range(h, d.dst.H, d.g.H, hlo, hhi);
-        adj_range(w, d.dst.W, d.g.W, wlo, whi);
-        for (int hh = hlo; hh <= hhi; ++hh) {
+        for (int q = 0; q < 8; ++q) {
+            const int hh = hh0 + q;
             int h0, h1; float lh;
-            bilin_src(hh, d.dst.H, d.g.H, h0, h1, lh);
-            float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
-            if (wh == 0.f) continue;
-            for (int ww = wlo; ww <= whi; ++ww) {
-                int w0, w1; float lw;
-                bilin_src(ww, d.dst.W, d.g.W, w0, w1, lw);
-                float wt = wh * ((w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f));
-                if (wt == 0.f) continue;
+            bilin_src(hh <= hhi ? hh : hhi, d.dst.H, d.g.H, h0, h1, lh);
+            wrow[q] = hh <= hhi ? ((h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f)) : 0.f;
+        }
+        for (int ww = wlo + (int)j; ww <= whi; ww += (int)S) {
+            int w0, w1; float lw;
+            bilin_src(ww, d.dst.W, d.g.W, w0, w1, lw);
+            const float wc = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+            if (wc == 0.f) continue;
+            // all 8 candidate rows are loaded unconditionally (clamped row, weight 0 outside the footprint): conditional
+            // loads would be serialised by the compiler's per-branch waitcnt
+            uint4 gr[8], mr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int hh = min(hh0 + q, hhi);
+                const size_t off = ((((size_t)n * d.g.H + hh) * d.g.W + ww) * d.g.Cp + d.g.c_off + g * E) * sizeof(T);
+                gr[q] = *(const uint4*)((const char*)d.g.ptr + off);
+                if (d.mask_mode == 1)
+                    mr[q] = *(const uint4*)((const char*)d.mask.ptr + ((((size_t)n * d.mask.H + hh) * d.mask.W + ww) * d.mask.Cp + d.mask.c_off + g * E) * sizeof(T));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float wt = wc * wrow[q];
                 float gv[E];
-                load_gran_f<T>(d.g, n, hh, ww, d.g.c_off + g * E, gv);
+                Gran<T>::unpack(gr[q], gv);
                 if (d.mask_mode == 1) {
                     float m[E];
-                    load_gran_f<T>(d.mask, n, hh, ww, d.mask.c_off + g * E, m);
+                    Gran<T>::unpack(mr[q], m);
 #pragma unroll
                     for (int e = 0; e < E; ++e) gv[e] = m[e] > 0.f ? gv[e] : 0.f;
                 }
@@ -448,6 +475,14 @@ __global__ __launch_bounds__(256) void mask_add_kernel(mfc_maskadd_desc d, long 
                 for (int e = 0; e < E; ++e) acc[e] += wt * gv[e];
             }
         }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[e * 256 + tid] = live ? acc[e] : 0.f;
+    __syncthreads();
+    if (!live || j != 0) return;
+    for (unsigned k = 1; k < S; ++k) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += red[e * 256 + tid + k * Cg];
     }
     char* o = (char*)d.dst.ptr + ((((size_t)n * d.dst.H + h) * d.dst.W + w) * d.dst.Cp + d.dst.c_off + g * E) * sizeof(T);
     if (d.accumulate) {
@@ -464,20 +499,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void mask_add_same_kernel(mfc_maskadd_desc d, long total, int Cg) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 4;
-    const long base = ((long)blockIdx.x * 256) * U + threadIdx.x;
-    uint4 gr[U], mr[U], dr[U]; long pix[U]; int gq[U];
+    const unsigned base = (blockIdx.x * 256u) * U + threadIdx.x;      // (host guarantees total < 2^31)
+    uint4 gr[U], mr[U], dr[U]; unsigned pix[U]; int gq[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        long idx = base + (long)u * 256;
-        if (idx >= total) idx = total - 1;
-        gq[u] = (int)(idx % Cg); pix[u] = idx / Cg;
+        unsigned idx = base + u * 256u;
+        if (idx >= (unsigned)total) idx = (unsigned)total - 1;
+        pix[u] = idx / (unsigned)Cg; gq[u] = (int)(idx - pix[u] * (unsigned)Cg);
         gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
         if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
         if (d.accumulate) dr[u] = ld_lin<T>(d.dst, pix[u], d.dst.c_off + gq[u] * E);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if (base + (long)u * 256 >= total) break;
+        if (base + u * 256u >= (unsigned)total) break;
         float gv[E];
         Gran<T>::unpack(gr[u], gv);
         if (d.mask_mode == 1) {
@@ -504,6 +539,7 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
     if (d->mask_mode == 1 && (!view_ok(d->mask, E) || d->mask.H != d->g.H || d->mask.W != d->g.W)) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     const long total = (long)d->N * d->dst.H * d->dst.W * Cg;
+    if (total >= (1L << 31) - 2048 || (long)d->N * d->g.H * d->g.W * Cg >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     if (d->dst.H == d->g.H && d->dst.W == d->g.W) {
@@ -513,8 +549,17 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
         MFC_CHECK_LAUNCH();
         return MFC_OK;
     }
-    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(mask_add_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
-    else hipLaunchKernelGGL(mask_add_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    if (d->g.H < d->dst.H || d->g.W < d->dst.W) return MFC_ERR_UNSUPPORTED;      // the adjoint of an UP-sampling only
+    const int ratio = (d->g.H + d->dst.H - 1) / d->dst.H;
+    int LS = ratio >= 4 ? 3 : ratio >= 2 ? 2 : 1;                               // column lanes per output granule = 2^LS
+    while (LS > 0 && (Cg << LS) > 256) --LS;
+    if (Cg > 256) return MFC_ERR_UNSUPPORTED;
+    const int PB = 256 / (Cg << LS);
+    const long npo = (long)d->N * d->dst.H * d->dst.W;
+    const int blocksS = (int)((npo + PB - 1) / PB);
+    (void)blocks;
+    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(mask_add_kernel<bf16_t>, dim3(blocksS), dim3(256), 0, st, *d, npo, Cg, LS, PB);
+    else hipLaunchKernelGGL(mask_add_kernel<float>, dim3(blocksS), dim3(256), 0, st, *d, npo, Cg, LS, PB);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -522,36 +567,65 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
 // ------------------------------------------------------------------ bias gradient
 // db[c] += sum over pixels of dy[pix][c]   (db must be zero at step start)
 template <typename T>
-__global__ __launch_bounds__(256) void bias_grad_kernel(const T* dy, float* db, long npix, int Cp, int C, int CS, int pix_per_block) {
-    __shared__ float red[256];
-    const int cl = threadIdx.x % CS, prow = threadIdx.x / CS, PPI = blockDim.x / CS;
-    const int c = blockIdx.y * CS + cl;
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* dy, float* db, long npix, int Cp, int C, int Cg, int PPI, int pix_per_block) {
+    constexpr int E = Gran<T>::E;
+    constexpr int U = 4;                       // granules in flight per thread
+    __shared__ float red[256 * 8];
+    const int gi = threadIdx.x % Cg, prow = threadIdx.x / Cg;
+    const int ch = (blockIdx.y * Cg + gi) * E;
+    const bool live = ch < Cp;
     const long p0 = (long)blockIdx.x * pix_per_block;
     long p1 = p0 + pix_per_block; if (p1 > npix) p1 = npix;
-    float s = 0.f;
-    if (c < Cp)
-        for (long p = p0 + prow; p < p1; p += PPI) s += ld_elem<T>(dy + p * Cp + c);
-    red[threadIdx.x] = s;
+    float s[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    const int chc = live ? ch : 0;
+    for (long pp = p0 + prow; pp < p1; pp += (long)U * PPI) {
+        uint4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long q = pp + (long)u * PPI;
+            r[u] = *(const uint4*)(dy + (q < p1 ? q : p0 + prow) * Cp + chc);       // clamped: branch-free loads
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pp + (long)u * PPI < p1) {
+                float v[E];
+                Gran<T>::unpack(r[u], v);
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[e] += v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[threadIdx.x * E + e] = s[e];
     __syncthreads();
-    if (prow == 0 && c < C) {
-        float a = 0.f;
-        for (int q = 0; q < PPI; ++q) a += red[q * CS + cl];
-        atomicAdd(db + c, a);
+    if (prow == 0 && live) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float a = 0.f;
+            for (int q = 0; q < PPI; ++q) a += red[(q * Cg + gi) * E + e];
+            if (ch + e < C) atomicAdd(db + ch + e, a);
+        }
     }
 }
 
 extern "C" int mfc_bias_grad(const void* dy, float* db, int32_t dtype, int64_t npix, int32_t Cp, int32_t C, void* stream) {
-    if (!dy || !db || npix <= 0 || Cp <= 0 || C > Cp) return MFC_ERR_INVALID_ARG;
+    if (!dy || !db || npix <= 0 || Cp <= 0 || C > Cp || Cp % 8) return MFC_ERR_INVALID_ARG;
+    if (dtype != MFC_BF16 && dtype != MFC_F32) return MFC_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int nslab = (Cp + 255) / 256;
-    const int CS = (Cp + nslab - 1) / nslab;
-    const int PPI = 256 / CS;
-    long want = npix / 2048 + 1; if (want > 512) want = 512;
+    const int E = dtype == MFC_BF16 ? 8 : 4;
+    const int Cgt = Cp / E;                                // granules per pixel
+    // channel slabs of <= 16 granules: many pixel rows per workgroup, so few workgroups (= few same-address atomics) suffice
+    const int nslab = (Cgt + 15) / 16;
+    const int Cg = (Cgt + nslab - 1) / nslab;
+    const int PPI = 256 / Cg;
+    long want = npix / (16 * PPI) + 1; if (want > 1024 / nslab + 1) want = 1024 / nslab + 1;
     int ppb = (int)((npix + want - 1) / want);
+    ppb = ((ppb + PPI - 1) / PPI) * PPI;
     const int blocks = (int)((npix + ppb - 1) / ppb);
-    if (dtype == MFC_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(blocks, nslab), dim3(CS * PPI), 0, st, (const bf16_t*)dy, db, (long)npix, Cp, C, CS, ppb);
-    else if (dtype == MFC_F32) hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks, nslab), dim3(CS * PPI), 0, st, (const float*)dy, db, (long)npix, Cp, C, CS, ppb);
-    else return MFC_ERR_INVALID_ARG;
+    if (dtype == MFC_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(blocks, nslab), dim3(Cg * PPI), 0, st, (const bf16_t*)dy, db, (long)npix, Cp, C, Cg, PPI, ppb);
+    else hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks, nslab), dim3(Cg * PPI), 0, st, (const float*)dy, db, (long)npix, Cp, C, Cg, PPI, ppb);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -752,50 +826,87 @@ __global__ __launch_bounds__(256) void head_warp_scatter_kernel(mfc_headgather_d
     }
 }
 
+// one thread per low-resolution pixel of one clip b: accumulates the adjoint for ALL T frames at once (the T*nc gradient
+// channels of a full-resolution pixel are contiguous, so a tap is Cp/E granule loads instead of T*nc scalar ones); the
+// separable tap weights are computed once per row / column.
 template <typename T>
 __global__ __launch_bounds__(256) void head_gather_bwd_kernel(mfc_headgather_desc d, T* dl, const float* dU, long total) {
     constexpr int E = Gran<T>::E;
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one low-res pixel of one (t, b) map
+    constexpr int MAXC = 40;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;      // (b, hs, ws)
     if (idx >= total) return;
     const long HWs = (long)d.Hs * d.Ws;
-    const int tb = (int)(idx / HWs); const long r = idx - (long)tb * HWs;
+    const int b = (int)(idx / HWs); const long r = idx - (long)b * HWs;
     const int hs = (int)(r / d.Ws), ws = (int)(r - (long)hs * d.Ws);
-    const int t = tb / d.B, b = tb - t * d.B;
-    float acc[8];
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    const int TC = d.T * d.nc;                            // logit-gradient channels of xh (<= Cp <= 40)
+    float acc[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) acc[k] = 0.f;
     int hlo, hhi, wlo, whi;
     adj_range(hs, d.Hs, d.H, hlo, hhi);
     adj_range(ws, d.Ws, d.W, wlo, whi);
-    const bool fromU = (dU != nullptr) && t > 0;
     const int CU = (d.T - 1) * d.nc;
-    const T* G = (const T*)d.xh + (size_t)b * d.H * d.W * d.Cp + t * d.nc;
-    const float* GU = fromU ? dU + (size_t)b * d.H * d.W * CU + (t - 1) * d.nc : nullptr;
-    for (int hh = hlo; hh <= hhi; ++hh) {
-        int h0, h1; float lh;
-        bilin_src(hh, d.Hs, d.H, h0, h1, lh);
-        const float wh = (h0 == hs ? 1.f - lh : 0.f) + (h1 == hs ? lh : 0.f);
-        if (wh == 0.f) continue;
-        for (int ww = wlo; ww <= whi; ++ww) {
+    const char* G = (const char*)d.xh + (size_t)b * d.H * d.W * d.Cp * sizeof(T);
+    const float* GU = dU ? dU + (size_t)b * d.H * d.W * CU : nullptr;
+    // granules that hold logit gradients (with the warp only frame 0 comes from xh; acc[MAXC-1-k] then holds dU channel k)
+    const int ng = GU ? (d.nc + E - 1) / E : (TC + E - 1) / E;
+    for (int ww0 = wlo; ww0 <= whi; ww0 += 8) {
+        float wcol[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ww = ww0 + j;
             int w0, w1; float lw;
-            bilin_src(ww, d.Ws, d.W, w0, w1, lw);
-            const float wt = wh * ((w0 == ws ? 1.f - lw : 0.f) + (w1 == ws ? lw : 0.f));
-            if (wt == 0.f) continue;
-            if (fromU) {
-                const float* gp = GU + ((size_t)hh * d.W + ww) * CU;
-                for (int k = 0; k < d.nc; ++k) acc[k] += wt * gp[k];
-            } else {
-                const T* gp = G + ((size_t)hh * d.W + ww) * d.Cp;
-                for (int k = 0; k < d.nc; ++k) acc[k] += wt * ld_elem<T>(gp + k);
+            bilin_src(ww <= whi ? ww : whi, d.Ws, d.W, w0, w1, lw);
+            wcol[j] = ww <= whi ? ((w0 == ws ? 1.f - lw : 0.f) + (w1 == ws ? lw : 0.f)) : 0.f;
+        }
+        for (int hh = hlo; hh <= hhi; ++hh) {
+            int h0, h1; float lh;
+            bilin_src(hh, d.Hs, d.H, h0, h1, lh);
+            const float wh = (h0 == hs ? 1.f - lh : 0.f) + (h1 == hs ? lh : 0.f);
+            if (wh == 0.f) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float wt = wh * wcol[j];
+                if (wt == 0.f) continue;
+                const size_t pix = (size_t)hh * d.W + (ww0 + j);
+                const char* gp = G + pix * d.Cp * sizeof(T);
+#pragma unroll
+                for (int g = 0; g < MAXC / E; ++g) {
+                    if (g < ng) {
+                        float v[E];
+                        Gran<T>::unpack(*(const uint4*)(gp + g * 16), v);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) acc[g * E + e] += wt * v[e];
+                    }
+                }
+                if (GU) {       // warped frames (t >= 1): their adjoint comes from the scattered fp32 scratch instead
+                    const float* up = GU + pix * CU;
+#pragma unroll
+                    for (int k = 0; k < 30; ++k) if (k < CU) acc[MAXC - 1 - k] += wt * up[k];
+                }
             }
         }
     }
-    float o[8];
-    for (int k = 0; k < 8; ++k) o[k] = k < d.nc ? acc[k] : 0.f;
-    for (int g = 0; g < d.Lp / E; ++g) {
-        float z[E];
+    for (int t = 0; t < d.T; ++t) {
+        float o[8];
 #pragma unroll
-        for (int e = 0; e < E; ++e) z[e] = (g * E + e) < 8 ? o[g * E + e] : 0.f;
-        *(uint4*)((char*)dl + ((size_t)idx * d.Lp + g * E) * sizeof(T)) = Gran<T>::pack(z);
+        for (int k = 0; k < 8; ++k) {
+            float v = 0.f;
+            if (k < d.nc) {
+                // (dynamic register-array indexing is avoided: select with a compile-time unrolled scan)
+                const int src = (GU && t > 0) ? (MAXC - 1 - ((t - 1) * d.nc + k)) : (t * d.nc + k);
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q) v = (q == src) ? acc[q] : v;
+            }
+            o[k] = v;
+        }
+        T* op = dl + ((size_t)(t * d.B + b) * HWs + r) * d.Lp;
+        for (int g = 0; g < d.Lp / E; ++g) {
+            float z[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) z[e] = (g * E + e) < 8 ? o[(g * E + e) & 7] : 0.f;
+            *(uint4*)((char*)op + g * 16) = Gran<T>::pack(z);
+        }
     }
 }
 
@@ -814,7 +925,7 @@ extern "C" int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, 
         if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_warp_scatter_kernel<bf16_t>, dim3(blk), dim3(256), 0, st, *d, dU, tot);
         else hipLaunchKernelGGL(head_warp_scatter_kernel<float>, dim3(blk), dim3(256), 0, st, *d, dU, tot);
     }
-    const long total = (long)d->T * d->B * d->Hs * d->Ws;
+    const long total = (long)d->B * d->Hs * d->Ws;
     const int blocks = (int)((total + 255) / 256);
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, (bf16_t*)dlogits, (const float*)dU, total);
     else hipLaunchKernelGGL(head_gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, (float*)dlogits, (const float*)dU, total);

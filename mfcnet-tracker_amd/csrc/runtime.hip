@@ -195,40 +195,71 @@ extern "C" int mfc_prof_collect(mfc_prof_result* out) {
 extern "C" int mfc_op_size(void) { return (int)sizeof(mfc_op); }
 extern "C" const char* mfc_version(void) { return "mfcnet_hip 0.1 (gfx950)"; }
 
+static int run_one(const mfc_op& o, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (o.kind) {
+        case MFC_OP_CONV: return mfc_conv2d_fwd(&o.u.conv, stream);
+        case MFC_OP_WGRAD: return mfc_conv2d_wgrad(&o.u.wgrad, stream);
+        case MFC_OP_BNFIN: return mfc_bn_finalize(&o.u.bnfin, stream);
+        case MFC_OP_COMBINE: return mfc_combine_fwd(&o.u.combine, stream);
+        case MFC_OP_BNBWD_REDUCE: return mfc_bnbwd_reduce(&o.u.bnbwd, stream);
+        case MFC_OP_BNBWD_FIN: return mfc_bnbwd_finalize(&o.u.bnbwdfin, stream);
+        case MFC_OP_BNBWD_APPLY: return mfc_bnbwd_apply(&o.u.bnbwd, stream);
+        case MFC_OP_MASK_ADD: return mfc_mask_add(&o.u.maskadd, stream);
+        case MFC_OP_HEAD_FWD: return mfc_head_gather_fwd(&o.u.head, stream);
+        case MFC_OP_HEAD_BWD: return mfc_head_gather_bwd(&o.u.headbwd.d, (void*)o.u.headbwd.dlogits, stream);
+        case MFC_OP_BIAS_GRAD:   // a = dy, b = db, n = npix, i[0]=dtype, i[1]=Cp, i[2]=C
+            return mfc_bias_grad((const void*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.n, o.u.raw.i[1], o.u.raw.i[2], stream);
+        case MFC_OP_MEMSET:      // a = ptr, n = bytes
+            return hipMemsetAsync((void*)o.u.raw.a, 0, (size_t)o.u.raw.n, st) == hipSuccess ? MFC_OK : MFC_ERR_LAUNCH;
+        case MFC_OP_PACK:        // a = jobs, i[0]=njobs, i[1]=total_blocks, i[2]=dtype
+            return mfc_pack_weights((const mfc_pack_job*)o.u.raw.a, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], stream);
+        case MFC_OP_UNPACK:      // a = jobs, i[0]=njobs, i[1]=total_blocks
+            return mfc_unpack_wgrad((const mfc_unpack_job*)o.u.raw.a, o.u.raw.i[0], o.u.raw.i[1], stream);
+        case MFC_OP_NCHW2NHWC:   // a = src, b = dst, i = dtype,N,C,H,W,Cp,c_off
+            return mfc_nchw_to_nhwc((const float*)o.u.raw.a, (void*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3],
+                                    o.u.raw.i[4], o.u.raw.i[5], o.u.raw.i[6], 1, stream);
+        case MFC_OP_NHWC2NCHW:   // a = src, b = dst, i = dtype,N,C,H,W,Cp
+            return mfc_nhwc_to_nchw((const void*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3],
+                                    o.u.raw.i[4], o.u.raw.i[5], stream);
+        default: return MFC_ERR_INVALID_ARG;
+    }
+}
+
 extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
     if (!ops || n < 0) return MFC_ERR_INVALID_ARG;
-    hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < n; ++i) {
-        const mfc_op& o = ops[i];
-        int rc = MFC_ERR_UNSUPPORTED;
-        switch (o.kind) {
-            case MFC_OP_CONV: rc = mfc_conv2d_fwd(&o.u.conv, stream); break;
-            case MFC_OP_WGRAD: rc = mfc_conv2d_wgrad(&o.u.wgrad, stream); break;
-            case MFC_OP_BNFIN: rc = mfc_bn_finalize(&o.u.bnfin, stream); break;
-            case MFC_OP_COMBINE: rc = mfc_combine_fwd(&o.u.combine, stream); break;
-            case MFC_OP_BNBWD_REDUCE: rc = mfc_bnbwd_reduce(&o.u.bnbwd, stream); break;
-            case MFC_OP_BNBWD_FIN: rc = mfc_bnbwd_finalize(&o.u.bnbwdfin, stream); break;
-            case MFC_OP_BNBWD_APPLY: rc = mfc_bnbwd_apply(&o.u.bnbwd, stream); break;
-            case MFC_OP_MASK_ADD: rc = mfc_mask_add(&o.u.maskadd, stream); break;
-            case MFC_OP_HEAD_FWD: rc = mfc_head_gather_fwd(&o.u.head, stream); break;
-            case MFC_OP_HEAD_BWD: rc = mfc_head_gather_bwd(&o.u.headbwd.d, (void*)o.u.headbwd.dlogits, stream); break;
-            case MFC_OP_BIAS_GRAD:   // a = dy, b = db, n = npix, i[0]=dtype, i[1]=Cp, i[2]=C
-                rc = mfc_bias_grad((const void*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.n, o.u.raw.i[1], o.u.raw.i[2], stream); break;
-            case MFC_OP_MEMSET:      // a = ptr, n = bytes
-                rc = hipMemsetAsync((void*)o.u.raw.a, 0, (size_t)o.u.raw.n, st) == hipSuccess ? MFC_OK : MFC_ERR_LAUNCH; break;
-            case MFC_OP_PACK:        // a = jobs, i[0]=njobs, i[1]=total_blocks, i[2]=dtype
-                rc = mfc_pack_weights((const mfc_pack_job*)o.u.raw.a, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], stream); break;
-            case MFC_OP_UNPACK:      // a = jobs, i[0]=njobs, i[1]=total_blocks
-                rc = mfc_unpack_wgrad((const mfc_unpack_job*)o.u.raw.a, o.u.raw.i[0], o.u.raw.i[1], stream); break;
-            case MFC_OP_NCHW2NHWC:   // a = src, b = dst, i = dtype,N,C,H,W,Cp,c_off
-                rc = mfc_nchw_to_nhwc((const float*)o.u.raw.a, (void*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3],
-                                      o.u.raw.i[4], o.u.raw.i[5], o.u.raw.i[6], 1, stream); break;
-            case MFC_OP_NHWC2NCHW:   // a = src, b = dst, i = dtype,N,C,H,W,Cp
-                rc = mfc_nhwc_to_nchw((const void*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3],
-                                      o.u.raw.i[4], o.u.raw.i[5], stream); break;
-            default: rc = MFC_ERR_INVALID_ARG;
-        }
+        const int rc = run_one(ops[i], stream);
         if (rc != MFC_OK) return -(1000 * (i + 1)) + rc;
     }
     return MFC_OK;
+}
+
+// Tuning aid: run the program with a HIP event between consecutive records (each record `reps` times back to back) and
+// return the stream time of every record in ms_out[n] (per repetition).  Synchronises the stream.
+extern "C" int mfc_program_profile(const mfc_op* ops, int32_t n, int32_t reps, float* ms_out, void* stream) {
+    if (!ops || n <= 0 || !ms_out || reps < 1) return MFC_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t* ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * (size_t)(n + 1));
+    if (!ev) return MFC_ERR_INVALID_ARG;
+    for (int i = 0; i <= n; ++i) (void)hipEventCreate(&ev[i]);
+    int rc = MFC_OK;
+    for (int i = 0; i < n && rc == MFC_OK; ++i) {
+        (void)hipEventRecord(ev[i], st);
+        for (int r = 0; r < reps && rc == MFC_OK; ++r) {
+            rc = run_one(ops[i], stream);
+            if (rc != MFC_OK) rc = -(1000 * (i + 1)) + rc;
+        }
+    }
+    (void)hipEventRecord(ev[n], st);
+    (void)hipStreamSynchronize(st);
+    if (rc == MFC_OK)
+        for (int i = 0; i < n; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            ms_out[i] = ms / (float)reps;
+        }
+    for (int i = 0; i <= n; ++i) (void)hipEventDestroy(ev[i]);
+    free(ev);
+    return rc;
 }

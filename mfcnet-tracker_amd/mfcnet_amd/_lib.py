@@ -128,7 +128,7 @@ class Op(C.Structure):
 EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_unpack_wgrad",
            "mfc_bn_finalize", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
-           "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_bwd", "mfc_adam_step", "mfc_program_run",
+           "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_bwd", "mfc_adam_step", "mfc_program_run", "mfc_program_profile",
            "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect"]
 
 
@@ -149,6 +149,7 @@ def _load():
         if name not in ("mfc_version",):
             getattr(lib, name).restype = C.c_int
     lib.mfc_program_run.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.mfc_program_profile.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mfc_bias_grad.argtypes = [vp, vp, i32, C.c_int64, i32, i32, vp]
     lib.mfc_nchw_to_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.mfc_nhwc_to_nchw.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
