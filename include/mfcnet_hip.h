@@ -120,14 +120,18 @@ int mfc_pack_weights(const mfc_pack_job* jobs_dev, int32_t njobs, int32_t total_
 
 /* ------------------------------------------------------------------------------------
  * Weight gradient.  Replaces the cuDNN wgrad of every conv above under loss.backward().
- *   dWp[a,b][co][ci] += sum_{n,i,j} dy[n,i,j,co] * f(x[n, i*s+dh0+a, j*s+dw0+b, ci])
- * accumulated with fp32 atomics into a packed image [TA*TB][Cout16][Cin16] that must be
- * zero at step start; mfc_unpack_wgrad converts all images to the reference layout.
+ *   dWp[a,b][co][ci] = sum_{n,i,j} dy[n,i,j,co] * f(x[n, i*s+dh0+a, j*s+dw0+b, ci])
+ * The pixel axis is split over `parts` workgroup sets; set s WRITES (plain stores, no atomics:
+ * deterministic, and ~10x cheaper than fp32 atomics on a 36 KiB image shared by 300 workgroups)
+ * its partial sum into slice s of dwp = fp32 [parts][TA*TB][Cout16][Cin16].  mfc_conv2d_wgrad_parts
+ * returns the number of slices a launch of `d` writes (size dwp with it; the buffer must have
+ * been zeroed once, ever: cells outside the channel blocks are never written).
+ * mfc_unpack_wgrad sums the slices and converts all images to the reference layout.
  * ------------------------------------------------------------------------------------ */
 typedef struct {
     const void* x;           /* T [N, Hin, Win, Cin_p] conv input (pre input-transform) */
     const void* dy;          /* T [N, Hout, Wout, Cout_p] */
-    float* dwp;              /* fp32 [TA*TB][Co16][Ci16] */
+    float* dwp;              /* fp32 [parts][TA*TB][Co16][Ci16] partial sums (see above) */
     const float* in_coef;    /* as in mfc_conv_desc */
     int32_t dtype;
     int32_t N, Hin, Win, Cin_p, Cin;
@@ -135,15 +139,17 @@ typedef struct {
     int32_t TA, TB, dh0, dw0, in_stride;
     int32_t in_relu, images_per_group;
     int32_t TH, TW;
-    int32_t splits;          /* pixel splits (grid.x); 0 = choose */
+    int32_t splits;          /* pixel splits (= parts); 0 = choose */
 } mfc_wgrad_desc;
 int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream);
+int mfc_conv2d_wgrad_parts(const mfc_wgrad_desc* d);      /* > 0: slices written; < 0: error */
 
 typedef struct {
-    uint64_t src;            /* const float* packed [TA*TB][Co16][Ci16] */
+    uint64_t src;            /* const float* packed partial sums [nparts][TA*TB][Co16][Ci16] */
     uint64_t dst;            /* float* [Cout][Cin][KH][KW] gradient (overwritten) */
     int32_t Cout, Cin, KH, KW, Co16, Ci16;
-    int32_t block0, nblocks;
+    int32_t block0, nblocks; /* nblocks = ceil(KH*KW*Co16*Ci16 / 256): one thread per packed cell */
+    int32_t nparts, pad_;
 } mfc_unpack_job;
 int mfc_unpack_wgrad(const mfc_unpack_job* jobs_dev, int32_t njobs, int32_t total_blocks, void* stream);
 

@@ -19,6 +19,7 @@ static int g_wgrad_ksplit = 0;      // tuning: mfc_set_flag(3, 1) forces gc = gi
 int mfc_conv_set_force_mt(int v);
 int mfc_conv_set_grid(int v);
 int mfc_conv_set_ablate(int v);
+static int g_wgrad_ablate = 0;
 int mfc_conv_set_lds_kb(int v);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
@@ -27,6 +28,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 4) return mfc_conv_set_grid(value);
     if (id == 5) return mfc_conv_set_ablate(value);
     if (id == 6) return mfc_conv_set_lds_kb(value);
+    if (id == 7) { g_wgrad_ablate = value; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
 
@@ -38,6 +40,7 @@ struct WgradK {
     int Co16, Ci16, NCO, NCI, co_blocks, ci_blocks;
     int PW, pitch_d, pitch_x, off_x, off_tab;
     int ntile_mm, cnt;      // accumulator tiles per block, per wave
+    int slice;              // floats per partial-sum slice of dwp
 };
 
 template <typename T, int TPW, bool TR>
@@ -208,9 +211,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
     for (int i = 0; i < TPW; ++i) {
         const int* tt = ttab + (wave * TPW + i) * 4;
         if (i < p.cnt && tt[3]) {
-            float* o = p.dwp + tt[2] + (size_t)((lane >> 4) * 4) * p.Ci16 + (lane & 15);
+            float* o = p.dwp + (size_t)blockIdx.x * p.slice + tt[2] + (size_t)((lane >> 4) * 4) * p.Ci16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(o + (size_t)r * p.Ci16, acc[i][r]);
+            for (int r = 0; r < 4; ++r) o[(size_t)r * p.Ci16] = acc[i][r];
         }
     }
 }
@@ -237,6 +240,7 @@ struct WgradF {
     int gc, gi, gk;                   // wave arrangement
     int gd, gx;                       // granules per pixel staged for dy / x
     int PW, pitch_d, pitch_x, buf_bytes, off_x, off_tab, off_coef, G;
+    int slice;                        // floats per partial-sum slice of dwp
 };
 
 template <int TB, int WCO, int WCI, bool BIG>
@@ -455,9 +459,9 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_fast_kernel(Wgrad
                 for (int j = 0; j < WCI; ++j) {
                     const int co = co0 + cow + i * 16 + (lane >> 4) * 4, ci = ci0 + ciw + j * 16 + (lane & 15);
                     if (co < p.Co16 && ci < p.Ci16) {
-                        float* o = p.dwp + ((size_t)(a * TB + b) * p.Co16 + co) * p.Ci16 + ci;
+                        float* o = p.dwp + (size_t)bsplit * p.slice + ((size_t)(a * TB + b) * p.Co16 + co) * p.Ci16 + ci;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(o + (size_t)r * p.Ci16, acc[b][i][j][r]);
+                        for (int r = 0; r < 4; ++r) o[(size_t)r * p.Ci16] = acc[b][i][j][r];
                     }
                 }
     }
@@ -477,6 +481,8 @@ struct WgradW {
     int TH, TW, tilesY, tilesX, ntiles, splits;     // sub-tile (TH*TW <= 32)
     int Co16, Ci16, co_blocks, ci_blocks;
     int gd, gx, PW, PHX, pitch_d, pitch_x, off_x, buf_bytes, wave_bytes, off_tab, off_coef;
+    int slice;       // floats per partial-sum slice of dwp
+    int ablate;      // tuning only: 1 skip global loads, 2 skip LDS staging stores, 4 skip LDS reads + MFMAs, 8 skip reduction + atomics
 };
 
 template <int TAA, int TB, int WCO, int WCI, int XP>
@@ -510,23 +516,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
             coefs[i] = (ci0 + ch < p.Cin_p) ? p.in_coef[((size_t)g * 4 + w) * p.Cin_p + ci0 + ch] : 0.f;
         }
     }
-    // per-lane staging pieces: idx = lane + i*64 -> (pixel, granule); packed gi | px<<4 | ty<<12, bit 30 = zero row/granule
+    // per-lane staging pieces: idx = lane + i*64 -> (pixel, granule); packed gi | px<<4 | ty<<12.  Every piece has
+    //   *_lds : its LDS byte offset inside a staging buffer -- pieces that never carry data (beyond the sub-tile / the
+    //           channel range) point at a dummy slot; their real slots are zeroed once below and never written again
+    //   *_vof : its byte offset from the first pixel of an INTERIOR tile (wave-uniform base + constant lane offset: the
+    //           main loop then spends no vector instruction on addresses)
     const int npx = p.PHX * p.PW;               // staged input rows: ((TH-1)*s + TAA) x PW
-    int dpk[DP], xpk[XP];
+    const int dummy = p.buf_bytes - 16;         // (host pads every buffer by 16 B)
+    int dpk[DP], xpk[XP], d_lds[DP], x_lds[XP], d_vof[DP], x_vof[XP];
+    unsigned dstat = 0, xstat = 0;              // bit i: piece i can carry data
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
         const int idx = lane + i * 64;
         const int pp = idx / p.gd, gi = idx - pp * p.gd;
         const int ty = pp / p.TW, tx = pp - ty * p.TW;
-        dpk[i] = (pp < 32) ? (gi | (tx << 4) | (ty << 12) | ((pp >= p.TH * p.TW || (co0 + gi * E) >= p.Cout_p) ? (1 << 30) : 0)) : -1;
+        const bool ok = pp < p.TH * p.TW && (co0 + gi * E) < p.Cout_p;
+        dpk[i] = gi | (tx << 4) | (ty << 12);
+        dstat |= (ok ? 1u : 0u) << i;
+        d_lds[i] = ok ? pp * p.pitch_d + gi * 16 : dummy;
+        d_vof[i] = ok ? ((ty * p.Wout + tx) * p.Cout_p * (int)sizeof(T) + gi * 16) : 0;
     }
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
         const int idx = lane + i * 64;
         const int pix = idx / p.gx, gi = idx - pix * p.gx;
         const int ty = pix / p.PW, px = pix - ty * p.PW;
-        xpk[i] = (pix < npx) ? (gi | (px << 4) | (ty << 12) | (((ci0 + gi * E) >= p.Cin_p) ? (1 << 30) : 0)) : -1;
+        const bool ok = pix < npx && (ci0 + gi * E) < p.Cin_p;
+        xpk[i] = gi | (px << 4) | (ty << 12);
+        xstat |= (ok ? 1u : 0u) << i;
+        x_lds[i] = ok ? p.off_x + pix * p.pitch_x + gi * 16 : dummy;
+        x_vof[i] = ok ? ((ty * p.Win + px) * p.Cin_p * (int)sizeof(T) + gi * 16) : 0;
     }
+    for (int o = lane * 16; o < p.wave_bytes; o += 64 * 16) *(uint4*)(wbase + o) = make_uint4(0, 0, 0, 0);
 
     f32x4 acc[TAA * TB][WCO][WCI];
 #pragma unroll
@@ -537,86 +558,101 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
             for (int j = 0; j < WCI; ++j) acc[b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4 dreg[DP], xreg[XP]; unsigned dmask = 0, xmask = 0;
-    int x_grp = 0;
+    int x_grp = 0; bool interior = false;
     const bool xf = (p.in_coef != nullptr);
+    const float relu_floor = p.in_relu ? 0.f : -3.0e38f;
 
-    auto load_tile = [&](int tile) {
-        const int txi = tile % p.tilesX; int r = tile / p.tilesX;
-        const int tyi = r % p.tilesY; const int n = r / p.tilesY;
-        const int i0 = tyi * p.TH, j0 = txi * p.TW;
-        dmask = 0; xmask = 0;
+    // tile coordinates are tracked incrementally (stride decomposed once: no division per tile)
+    const int stride = p.splits * 4;
+    const int st_x = stride % p.tilesX, st_y = (stride / p.tilesX) % p.tilesY, st_n = stride / (p.tilesX * p.tilesY);
+    struct TC { int n, tyi, txi; };
+    auto tc_next = [&](TC c) {
+        c.txi += st_x; if (c.txi >= p.tilesX) { c.txi -= p.tilesX; ++c.tyi; }
+        c.tyi += st_y; if (c.tyi >= p.tilesY) { c.tyi -= p.tilesY; ++c.n; }
+        c.n += st_n;
+        return c;
+    };
+
+    auto load_tile = [&](const TC& c) {
+        const int n = c.n, i0 = c.tyi * p.TH, j0 = c.txi * p.TW;
         x_grp = n / p.ipg;
-        const char* dbase = p.dy + ((size_t)n * p.Hout * p.Wout * p.Cout_p + co0) * sizeof(T);
-#pragma unroll
-        for (int i = 0; i < DP; ++i) {
-            const int oi = i0 + ((dpk[i] >> 12) & 0xff), oj = j0 + ((dpk[i] >> 4) & 0xff);
-            const bool inr = dpk[i] >= 0 && !(dpk[i] & (1 << 30)) && oi < p.Hout && oj < p.Wout;
-            const int oic = min(oi, p.Hout - 1), ojc = min(oj, p.Wout - 1);
-            const int gic = ((co0 + (dpk[i] & 15) * E) < p.Cout_p) ? (dpk[i] & 15) : 0;
-            dreg[i] = *(const uint4*)(dbase + (size_t)(oic * p.Wout + ojc) * (p.Cout_p * (int)sizeof(T)) + gic * 16);
-            dmask |= (inr ? 1u : 0u) << i;
-        }
-        const char* xbase = p.x + ((size_t)n * p.Hin * p.Win * p.Cin_p + ci0) * sizeof(T);
         const int ihb = i0 * p.s + p.dh0 + a, iwb = j0 * p.s + p.dw0;
+        interior = i0 + p.TH <= p.Hout && j0 + p.TW <= p.Wout && ihb >= 0 && ihb + p.PHX <= p.Hin && iwb >= 0 && iwb + p.PW <= p.Win;
+        const char* dimg = p.dy + ((size_t)n * p.Hout * p.Wout * p.Cout_p + co0) * sizeof(T);
+        const char* ximg = p.x + ((size_t)n * p.Hin * p.Win * p.Cin_p + ci0) * sizeof(T);
+        if (interior) {
+            const char* dt = dimg + (size_t)(i0 * p.Wout + j0) * (p.Cout_p * (int)sizeof(T));
+            const char* xt = ximg + (size_t)(ihb * p.Win + iwb) * (p.Cin_p * (int)sizeof(T));
 #pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            const int ih = ihb + ((xpk[i] >> 12) & 0xff), iw = iwb + ((xpk[i] >> 4) & 0xff);
-            const bool inr = xpk[i] >= 0 && !(xpk[i] & (1 << 30)) && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win;
-            const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
-            const int gic = ((ci0 + (xpk[i] & 15) * E) < p.Cin_p) ? (xpk[i] & 15) : 0;
-            xreg[i] = *(const uint4*)(xbase + (size_t)(ihc * p.Win + iwc) * (p.Cin_p * (int)sizeof(T)) + gic * 16);
-            xmask |= (inr ? 1u : 0u) << i;
+            for (int i = 0; i < DP; ++i) dreg[i] = *(const uint4*)(dt + (unsigned)d_vof[i]);
+#pragma unroll
+            for (int i = 0; i < XP; ++i) xreg[i] = *(const uint4*)(xt + (unsigned)x_vof[i]);
+        } else {
+            dmask = 0; xmask = 0;
+            const int drow = p.Cout_p * (int)sizeof(T), xrow = p.Cin_p * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < DP; ++i) {
+                const int oi = i0 + ((dpk[i] >> 12) & 0xff), oj = j0 + ((dpk[i] >> 4) & 0xff);
+                const bool inr = ((dstat >> i) & 1u) && oi < p.Hout && oj < p.Wout;
+                const int oic = min(oi, p.Hout - 1), ojc = min(oj, p.Wout - 1);
+                const int gic = ((dstat >> i) & 1u) ? (dpk[i] & 15) : 0;
+                dreg[i] = *(const uint4*)(dimg + (unsigned)((oic * p.Wout + ojc) * drow + gic * 16));
+                dmask |= (inr ? 1u : 0u) << i;
+            }
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int ih = ihb + ((xpk[i] >> 12) & 0xff), iw = iwb + ((xpk[i] >> 4) & 0xff);
+                const bool inr = ((xstat >> i) & 1u) && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+                const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
+                const int gic = ((xstat >> i) & 1u) ? (xpk[i] & 15) : 0;
+                xreg[i] = *(const uint4*)(ximg + (unsigned)((ihc * p.Win + iwc) * xrow + gic * 16));
+                xmask |= (inr ? 1u : 0u) << i;
+            }
         }
     };
+    // every lane stores every piece (no divergence): dead pieces go to the dummy slot
     auto store_tile = [&](char* buf) {
-        char* Ds = buf; char* Xs = buf + p.off_x;
 #pragma unroll
         for (int i = 0; i < DP; ++i) {
-            if (dpk[i] >= 0) {
-                const int row = ((dpk[i] >> 12) & 0xff) * p.TW + ((dpk[i] >> 4) & 0xff);
-                *(uint4*)(Ds + row * p.pitch_d + (dpk[i] & 15) * 16) = (dmask & (1u << i)) ? dreg[i] : make_uint4(0, 0, 0, 0);
-            }
+            uint4 v = dreg[i];
+            if (!interior && !(dmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
+            *(uint4*)(buf + d_lds[i]) = v;
         }
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            if (xpk[i] >= 0) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                const int gi = xpk[i] & 15;
-                if (xmask & (1u << i)) {
-                    v = xreg[i];
-                    if (xf) {
-                        const float* cf = coefs + (size_t)x_grp * 2 * (p.gx * 8) + gi * E;
-                        float f[E];
-                        Gran<T>::unpack(v, f);
+            uint4 v = xreg[i];
+            if (xf) {
+                const float* cf = coefs + (size_t)x_grp * 2 * (p.gx * 8) + (xpk[i] & 15) * E;
+                float f[E];
+                Gran<T>::unpack(v, f);
 #pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            float t = f[e] * cf[e] + cf[p.gx * 8 + e];
-                            f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
-                        }
-                        v = Gran<T>::pack(f);
-                    }
-                }
-                *(uint4*)(Xs + (((xpk[i] >> 12) & 0xff) * p.PW + ((xpk[i] >> 4) & 0xff)) * p.pitch_x + gi * 16) = v;
+                for (int e = 0; e < E; ++e) f[e] = fmaxf(f[e] * cf[e] + cf[p.gx * 8 + e], relu_floor);
+                v = Gran<T>::pack(f);
             }
+            if (!interior && !(xmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
+            *(uint4*)(buf + x_lds[i]) = v;
         }
     };
 
     typedef __attribute__((address_space(3))) s16x4 lds_s4;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     __syncthreads();                               // tables + coefficients visible
-    const int stride = p.splits * 4;
     int tile = bsplit * 4 + wave;
-    if (tile < p.ntiles) { load_tile(tile); store_tile(wbase); }
+    TC tc;
+    { tc.txi = tile % p.tilesX; const int r = tile / p.tilesX; tc.tyi = r % p.tilesY; tc.n = r / p.tilesY; }
+    if (tile < p.ntiles) { load_tile(tc); store_tile(wbase); }
     const int pr0 = 8 * (lane >> 4) + ((lane & 15) >> 2);
     const int csub = (lane & 3) * 8;
     const int xo0 = xoff[pr0] + csub, xo1 = xoff[pr0 + 4] + csub;
     for (int it = 0; tile < p.ntiles; tile += stride, ++it) {
         const int nxt = tile + stride;
-        if (nxt < p.ntiles) load_tile(nxt);
+        tc = tc_next(tc);
+        if (nxt < p.ntiles && !(p.ablate & 1)) load_tile(tc);
         const char* Ds = wbase + (it & 1) * p.buf_bytes;
         const char* Xs = Ds + p.off_x;
         const char* dA0 = Ds + pr0 * p.pitch_d + csub;
         const char* dA1 = dA0 + 4 * p.pitch_d;
+        if (p.ablate & 4) { if (nxt < p.ntiles && !(p.ablate & 2)) store_tile(wbase + ((it + 1) & 1) * p.buf_bytes); continue; }
         bf16x8 af[WCO];
 #pragma unroll
         for (int i = 0; i < WCO; ++i) {
@@ -640,8 +676,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
                 for (int j = 0; j < WCI; ++j)
                     acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[b][i][j], 0, 0, 0);
         }
-        if (nxt < p.ntiles) store_tile(wbase + ((it + 1) & 1) * p.buf_bytes);
+        if (nxt < p.ntiles && !(p.ablate & 2)) store_tile(wbase + ((it + 1) & 1) * p.buf_bytes);
     }
+    if (p.ablate & 8) return;
     // ---- tree-reduce the four waves' accumulators through LDS, then one wave issues the atomics ----
     constexpr int NTW = TAA * TB * WCO * WCI;
     bool flusher = true;
@@ -680,9 +717,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
                 for (int j = 0; j < WCI; ++j) {
                     const int co = co0 + i * 16 + (lane >> 4) * 4, ci = ci0 + j * 16 + (lane & 15);
                     if (co < p.Co16 && ci < p.Ci16) {
-                        float* o = p.dwp + ((size_t)(a * TB + b) * p.Co16 + co) * p.Ci16 + ci;
+                        float* o = p.dwp + (size_t)bsplit * p.slice + ((size_t)(a * TB + b) * p.Co16 + co) * p.Ci16 + ci;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(o + (size_t)r * p.Ci16, acc[b][i][j][r]);
+                        for (int r = 0; r < 4; ++r) o[(size_t)r * p.Ci16] = acc[b][i][j][r];
                     }
                 }
     }
@@ -738,7 +775,7 @@ static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st)
 }
 
 // returns MFC_ERR_UNSUPPORTED when the geometry does not fit the fast kernel (caller falls back)
-static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st) {
+static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) {
     if (d->dtype != MFC_BF16 || !g_wgrad_use_tr) return MFC_ERR_UNSUPPORTED;
     if (d->TB != 1 && d->TB != 3 && d->TB != 11) return MFC_ERR_UNSUPPORTED;
     WgradF f;
@@ -789,6 +826,8 @@ static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st) {
     if (S > f.ntiles) S = f.ntiles;
     if (S < 1) S = 1;
     f.splits = S;
+    f.slice = d->TA * d->TB * f.Co16 * f.Ci16;
+    if (parts_only) { *parts_only = S; return MFC_OK; }      // (every WCO/WCI/TB combination reaching this point has an instantiation below)
     static const bool dbg = getenv("MFC_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[wgrad fast] TB%d WCO%d WCI%d g=%dx%dx%d Y=%d S=%d lds=%zu tile %dx%d\n", d->TB, WCO, WCI, f.gc, f.gi, f.gk, Y, S, lds, f.TH, f.TW);
 #define WGF(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return big ? wgrad_fast_launch<tb, a_, b_, true>(f, lds, Y, st) : wgrad_fast_launch<tb, a_, b_, false>(f, lds, Y, st);
@@ -831,7 +870,7 @@ static void choose_subtile(int Hl, int Wl, int& TH, int& TW, int max_patch = 0) 
     TH = bh; TW = bw;
 }
 
-static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st) {
+static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) {
     if (d->dtype != MFC_BF16 || !g_wgrad_use_tr || g_wgrad_ksplit == 2) return MFC_ERR_UNSUPPORTED;
     if (d->TB != 3 && d->TB != 11) return MFC_ERR_UNSUPPORTED;
     WgradW f;
@@ -863,7 +902,8 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st) {
     const int nxp = ceil_div(f.PHX * f.PW * f.gx, 64);
     if (ceil_div(32 * f.gd, 64) > 3 || nxp > 7 || f.PW > 255) return MFC_ERR_UNSUPPORTED;
     const size_t ds = ((size_t)32 * f.pitch_d + 15) & ~(size_t)15, xs = ((size_t)f.PHX * f.PW * f.pitch_x + 15) & ~(size_t)15;
-    f.off_x = (int)ds; f.buf_bytes = (int)(ds + xs); f.wave_bytes = 2 * f.buf_bytes;
+    f.off_x = (int)ds; f.buf_bytes = (int)(ds + xs) + 16;      // + a 16-byte dummy slot (dead staging pieces)
+    f.wave_bytes = 2 * f.buf_bytes;
     size_t stage = (size_t)4 * f.wave_bytes;
     const size_t need = (size_t)2 * TAA * d->TB * WCO * WCI * 1024;      // tree reduction scratch (2 dumping waves)
     if (stage < need) stage = need;
@@ -872,10 +912,13 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st) {
     if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
     const int Y = (f.TA / TAA) * f.co_blocks * f.ci_blocks;
     int S = d->splits;
-    if (S <= 0) S = ceil_div(d->TB == 11 ? 512 : 320, Y);   // ~1.25 workgroups per CU: every extra workgroup is one more atomic flush (measured sweep)
+    if (S <= 0) S = ceil_div(512, Y);      // 2 workgroups per CU (the flush is a plain store of the partial sums: extra workgroups are cheap)
     if (S * 4 > f.ntiles) S = ceil_div(f.ntiles, 4);
     if (S < 1) S = 1;
     f.splits = S;
+    f.slice = d->TA * d->TB * f.Co16 * f.Ci16;
+    if (parts_only) { *parts_only = S; return MFC_OK; }
+    f.ablate = g_wgrad_ablate;
     if (alltaps) return wgrad_wave_launch<3, 3, 2, 2, 4>(f, lds, Y, st);
 #define WGW(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return nxp <= 4 ? wgrad_wave_launch<1, tb, a_, b_, 4>(f, lds, Y, st) : wgrad_wave_launch<1, tb, a_, b_, 7>(f, lds, Y, st);
     WGW(3, 3, 3) WGW(3, 3, 2) WGW(3, 3, 1) WGW(3, 2, 3) WGW(3, 2, 2) WGW(3, 2, 1) WGW(3, 1, 3) WGW(3, 1, 2) WGW(3, 1, 1)
@@ -884,15 +927,15 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st) {
     return MFC_ERR_UNSUPPORTED;
 }
 
-extern "C" int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream) {
+static int wgrad_any(const mfc_wgrad_desc* d, void* stream, int* parts_only) {
     if (!d || !d->x || !d->dy || !d->dwp) return MFC_ERR_INVALID_ARG;
     if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
     if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin > d->Cin_p || d->Cout > d->Cout_p) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->TA <= 0 || d->TB <= 0 || d->in_stride < 1 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
     {
-        int rcf = wgrad_wave(d, (hipStream_t)stream);
+        int rcf = wgrad_wave(d, (hipStream_t)stream, parts_only);
         if (rcf != MFC_ERR_UNSUPPORTED) return rcf;
-        rcf = wgrad_fast(d, (hipStream_t)stream);
+        rcf = wgrad_fast(d, (hipStream_t)stream, parts_only);
         if (rcf != MFC_ERR_UNSUPPORTED) return rcf;
     }
     const int esz = d->dtype == MFC_BF16 ? 2 : 4;
@@ -928,6 +971,8 @@ extern "C" int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream) {
     if (S > k.ntiles) S = k.ntiles;
     if (S < 1) S = 1;
     k.splits = S;
+    k.slice = d->TA * d->TB * k.Co16 * k.Ci16;
+    if (parts_only) { *parts_only = S; return MFC_OK; }
     hipStream_t st = (hipStream_t)stream;
     const bool tr = g_wgrad_use_tr != 0;
     if (d->dtype == MFC_BF16) {
@@ -943,4 +988,17 @@ extern "C" int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream) {
     if (TPW == 8) return wgrad_launch<float, 8, false>(k, lds, Y, st);
     if (TPW == 16) return wgrad_launch<float, 16, false>(k, lds, Y, st);
     return wgrad_launch<float, 28, false>(k, lds, Y, st);
+}
+
+extern "C" int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream) { return wgrad_any(d, stream, nullptr); }
+
+extern "C" int mfc_conv2d_wgrad_parts(const mfc_wgrad_desc* d) {
+    if (!d) return MFC_ERR_INVALID_ARG;
+    mfc_wgrad_desc t = *d;                 // geometry only: placeholder pointers are accepted
+    if (!t.x) t.x = (const void*)16;
+    if (!t.dy) t.dy = (const void*)16;
+    if (!t.dwp) t.dwp = (float*)16;
+    int parts = 0;
+    const int rc = wgrad_any(&t, nullptr, &parts);
+    return rc < 0 ? rc : parts;
 }

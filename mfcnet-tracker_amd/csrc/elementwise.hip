@@ -449,25 +449,15 @@ __global__ __launch_bounds__(256) void mask_add_kernel(mfc_maskadd_desc d, long 
             bilin_src(ww, d.dst.W, d.g.W, w0, w1, lw);
             const float wc = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
             if (wc == 0.f) continue;
-            // all 8 candidate rows are loaded unconditionally (clamped row, weight 0 outside the footprint): conditional
-            // loads would be serialised by the compiler's per-branch waitcnt
-            uint4 gr[8], mr[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int hh = min(hh0 + q, hhi);
-                const size_t off = ((((size_t)n * d.g.H + hh) * d.g.W + ww) * d.g.Cp + d.g.c_off + g * E) * sizeof(T);
-                gr[q] = *(const uint4*)((const char*)d.g.ptr + off);
-                if (d.mask_mode == 1)
-                    mr[q] = *(const uint4*)((const char*)d.mask.ptr + ((((size_t)n * d.mask.H + hh) * d.mask.W + ww) * d.mask.Cp + d.mask.c_off + g * E) * sizeof(T));
-            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float wt = wc * wrow[q];
+                if (wt == 0.f) continue;
                 float gv[E];
-                Gran<T>::unpack(gr[q], gv);
+                load_gran_f<T>(d.g, n, hh0 + q, ww, d.g.c_off + g * E, gv);
                 if (d.mask_mode == 1) {
                     float m[E];
-                    Gran<T>::unpack(mr[q], m);
+                    load_gran_f<T>(d.mask, n, hh0 + q, ww, d.mask.c_off + g * E, m);
 #pragma unroll
                     for (int e = 0; e < E; ++e) gv[e] = m[e] > 0.f ? gv[e] : 0.f;
                 }

@@ -51,15 +51,28 @@ extern "C" int mfc_pack_weights(const mfc_pack_job* jobs_dev, int32_t njobs, int
     return MFC_OK;
 }
 
+// one thread per packed cell (tap, co, ci) [ci fastest: the slice reads are coalesced]: sums the partial-sum slices in a
+// fixed order (deterministic) and scatters the total into the reference layout
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const mfc_unpack_job* jobs, int njobs) {
     const mfc_unpack_job j = jobs[find_job(jobs, njobs, blockIdx.x)];
-    const long total = (long)j.Cout * j.Cin * j.KH * j.KW;
-    long idx = (long)(blockIdx.x - j.block0) * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int kk = j.KH * j.KW;
-    const int tap = (int)(idx % kk); long r = idx / kk;
-    const int ci = (int)(r % j.Cin); const int co = (int)(r / j.Cin);
-    ((float*)j.dst)[idx] = ((const float*)j.src)[((size_t)tap * j.Co16 + co) * j.Ci16 + ci];
+    const int slice = j.KH * j.KW * j.Co16 * j.Ci16;
+    const int idx = (blockIdx.x - j.block0) * 256 + threadIdx.x;
+    if (idx >= slice) return;
+    const int ci = idx % j.Ci16; int r = idx / j.Ci16;
+    const int co = r % j.Co16; const int tap = r / j.Co16;
+    if (co >= j.Cout || ci >= j.Cin) return;
+    const float* src = (const float*)j.src + idx;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    int q = 0;
+    for (; q + 8 <= j.nparts; q += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += src[(size_t)(q + k) * slice];
+    }
+    for (; q < j.nparts; ++q) s[0] += src[(size_t)q * slice];
+    const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    ((float*)j.dst)[((size_t)co * j.Cin + ci) * (j.KH * j.KW) + tap] = tot;
 }
 
 extern "C" int mfc_unpack_wgrad(const mfc_unpack_job* jobs_dev, int32_t njobs, int32_t total_blocks, void* stream) {

@@ -58,7 +58,7 @@ class WgradDesc(C.Structure):
 
 class UnpackJob(C.Structure):
     _fields_ = [("src", u64), ("dst", u64), ("Cout", i32), ("Cin", i32), ("KH", i32), ("KW", i32),
-                ("Co16", i32), ("Ci16", i32), ("block0", i32), ("nblocks", i32)]
+                ("Co16", i32), ("Ci16", i32), ("block0", i32), ("nblocks", i32), ("nparts", i32), ("pad_", i32)]
 
 
 class BnFinDesc(C.Structure):
@@ -125,7 +125,7 @@ class Op(C.Structure):
 
 
 # every symbol include/mfcnet_hip.h declares
-EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_unpack_wgrad",
+EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_conv2d_wgrad_parts", "mfc_unpack_wgrad",
            "mfc_bn_finalize", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_bwd", "mfc_adam_step", "mfc_program_run", "mfc_program_profile",
@@ -162,6 +162,7 @@ def _load():
                  "mfc_loss_bwd"):
         getattr(lib, name).argtypes = [vp, vp]
     lib.mfc_conv2d_lds_bytes.argtypes = [vp]
+    lib.mfc_conv2d_wgrad_parts.argtypes = [vp]
     lib.mfc_conv2d_layout.argtypes = [vp, vp]
     lib.mfc_set_flag.argtypes = [i32, i32]
     lib.mfc_prof_enable.argtypes = [i32]
@@ -177,6 +178,14 @@ lib = _load()
 def check(rc: int, what: str = "mfc call"):
     if rc != 0:
         raise MfcError(f"{what} failed with status {rc}")
+
+
+def wgrad_parts(desc) -> int:
+    """Number of partial-sum slices mfc_conv2d_wgrad writes for `desc` (sizes its dwp buffer)."""
+    n = lib.mfc_conv2d_wgrad_parts(C.byref(desc))
+    if n <= 0:
+        raise MfcError(f"mfc_conv2d_wgrad_parts failed with status {n}")
+    return n
 
 
 def stream_ptr():

@@ -48,7 +48,7 @@ def _run_jobs(jobs, cls, fn, *extra):
         for k, v in j.items():
             setattr(arr[i], k, v)
         total = ((j["TA"] // j["TAS"]) * j["nchunks"] * j["Yblocks"] * j["nslots"] * j["NT16"] if cls is L.PackJob
-                 else j["Cout"] * j["Cin"] * j["KH"] * j["KW"])
+                 else j["KH"] * j["KW"] * j["Co16"] * j["Ci16"])
         arr[i].block0, arr[i].nblocks = b0, -(-total // 256)
         b0 += arr[i].nblocks
     dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
@@ -138,12 +138,14 @@ def conv2d_wgrad(x, dy, Cout, Cin, k, stride=1, in_coef=None, in_relu=False, ipg
     _, Ho, Wo, Cop = dy.shape
     pad = k // 2
     Co16, Ci16 = rup(Cout, 16), rup(Cin, 16)
-    dwp = torch.zeros(k * k * Co16 * Ci16, dtype=torch.float32, device="cuda")
-    d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), in_coef.data_ptr() if in_coef is not None else 0, dt_of(x),
+    d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), 0, in_coef.data_ptr() if in_coef is not None else 0, dt_of(x),
                     N, H, W, Cp, Cin, Ho, Wo, Cop, Cout, k, k, -pad, -pad, stride, 1 if in_relu else 0, ipg or N, 0, 0, splits)
+    parts = L.wgrad_parts(d)
+    dwp = torch.zeros(parts * k * k * Co16 * Ci16, dtype=torch.float32, device="cuda")      # partial-sum slices
+    d.dwp = dwp.data_ptr()
     L.call(L.lib.mfc_conv2d_wgrad, d)
     dw = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device="cuda")
-    _run_jobs([dict(src=dwp.data_ptr(), dst=dw.data_ptr(), Cout=Cout, Cin=Cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16)],
+    _run_jobs([dict(src=dwp.data_ptr(), dst=dw.data_ptr(), Cout=Cout, Cin=Cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16, nparts=parts)],
               L.UnpackJob, L.lib.mfc_unpack_wgrad)
     return dw
 

@@ -102,6 +102,7 @@ class ConvInfo:
     bias: Optional[str]
     dgrad: List = field(default_factory=list)     # data-gradient launch descriptors (1 for stride 1, 4 parity classes for stride 2)
     dwp: int = 0
+    wg: Optional[object] = None                   # weight-gradient launch descriptor (x / dy pointers filled at backward emission)
 
 
 class Plan:
@@ -125,6 +126,7 @@ class Plan:
             a.base = rup(a.buf.data_ptr(), 256)
         self.arenas["misc"].buf.zero_()
         self.arenas["act"].buf.zero_()
+        self.arenas["dwp"].buf.zero_()        # once: cells outside the channel blocks are never written by the wgrad launches
         self._build()                       # real pass: pointers
         self._finalize()
 
@@ -175,7 +177,7 @@ class Plan:
         self.pack_jobs.append(job)
         desc.wp = dst
 
-    def conv_info(self, fwd_desc, xt, y, wname, cout, cin, k, stride, bias) -> ConvInfo:
+    def conv_info(self, fwd_desc, xt, y, wname, cout, cin, k, stride, bias, in_coef=0, in_relu=0) -> ConvInfo:
         ci = ConvInfo(wname, cout, cin, k, stride, k // 2, (wname[:-6] + "bias") if bias else None)
         pad = ci.pad
         src = self.pptr(wname)
@@ -202,8 +204,15 @@ class Plan:
                             self._pack(d, src, cout, cin, k, TA=ta, TB=tb, kh0=kh0, kh_step=-2, kw0=kw0, kw_step=-2, mode=1)
                             ci.dgrad.append(d)
             Co16, Ci16 = rup(cout, 16), rup(cin, 16)
-            ci.dwp = self._alloc("dwp", k * k * Co16 * Ci16 * 4)
-            self.unpack_jobs.append(dict(src=ci.dwp, dst=self.gptr(wname), Cout=cout, Cin=cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16))
+            # the pixel axis is split over `parts` workgroup sets, each writing its own partial-sum slice (no atomics);
+            # the unpack job adds the slices up
+            ci.wg = L.WgradDesc(16, 16, 16, in_coef, self.dtype, xt.N, xt.H, xt.W, xt.Cp, xt.C, y.H, y.W, y.Cp, cout, k, k, -pad, -pad,
+                                stride, in_relu, xt.ipg, 0, 0, 0)
+            parts = L.wgrad_parts(ci.wg)
+            ci.dwp = self._alloc("dwp", parts * k * k * Co16 * Ci16 * 4)
+            ci.wg.dwp = ci.dwp
+            self.unpack_jobs.append(dict(src=ci.dwp, dst=self.gptr(wname), Cout=cout, Cin=cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16,
+                                         nparts=parts))
         return ci
 
     @staticmethod
@@ -224,7 +233,7 @@ class Plan:
                        bn.stats if (bn and bn.training) else 0, self.dtype, xt.N, xt.H, xt.W, xt.Cp, xt.C,
                        Ho, Wo, y.Cp, cout, Ho, Wo, k, k, -pad, -pad, stride, 1, 1, 0, 0,
                        1 if x.relu else 0, xt.ipg, 0, 0, 0)
-        ci = self.conv_info(d, xt, y, wname, cout, xt.C, k, stride, bias)
+        ci = self.conv_info(d, xt, y, wname, cout, xt.C, k, stride, bias, x.bn.coef if x.bn else 0, 1 if x.relu else 0)
         self.fwd.append((L.OP_CONV, d))
         self.ops.append(("conv", x, y, ci, bn))
         if bn:
@@ -475,9 +484,8 @@ class Plan:
                 assert y.grad_init, y.name
                 xt = x.t
                 k, s, pad = ci.k, ci.stride, ci.pad
-                self.bwd.append((L.OP_WGRAD, L.WgradDesc(xt.ptr, dy.ptr, ci.dwp, x.bn.coef if x.bn else 0, self.dtype, xt.N, xt.H,
-                                                         xt.W, xt.Cp, xt.C, y.H, y.W, y.Cp, ci.cout, k, k, -pad, -pad, s,
-                                                         1 if x.relu else 0, xt.ipg, 0, 0, 0)))
+                ci.wg.x, ci.wg.dy = xt.ptr, dy.ptr
+                self.bwd.append((L.OP_WGRAD, ci.wg))
                 if ci.bias:
                     r = L.RawOp(dy.ptr, self.gptr(ci.bias), 0, y.N * y.H * y.W)
                     r.i[0:3] = [self.dtype, y.Cp, ci.cout]
@@ -502,7 +510,7 @@ class Plan:
             if cls is L.PackJob:
                 total = (j["TA"] // j["TAS"]) * j["nchunks"] * j["Yblocks"] * j["nslots"] * j["NT16"]
             else:
-                total = j["Cout"] * j["Cin"] * j["KH"] * j["KW"]
+                total = j["KH"] * j["KW"] * j["Co16"] * j["Ci16"]
             nb = -(-total // per_block)
             arr[i].block0, arr[i].nblocks = b0, nb
             b0 += nb
@@ -529,7 +537,7 @@ class Plan:
         self.fwd_prog = self._program(pro + self.fwd)
         if self.need_backward:
             self._unpack_dev, nup, nbu = self._jobs(self.unpack_jobs, L.UnpackJob, 256)
-            pro = [(L.OP_MEMSET, L.RawOp(bs.base, 0, 0, bs.size)), (L.OP_MEMSET, L.RawOp(dw.base, 0, 0, dw.size)),
+            pro = [(L.OP_MEMSET, L.RawOp(bs.base, 0, 0, bs.size)),
                    (L.OP_MEMSET, L.RawOp(self.grad_base, 0, 0, self.m._G.numel() * 4))]
             r = L.RawOp(self._unpack_dev.data_ptr(), 0, 0, 0)
             r.i[0:2] = [nup, nbu]

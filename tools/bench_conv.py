@@ -54,9 +54,10 @@ def main():
                 line += f" | fwd-{label} {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF"
         if what in ("wgrad", "both"):
             dy = torch.randn(N, Ho, Wo, ops.rup(Cout, 8), device="cuda").to(dt)
-            dwp = torch.zeros(k * k * ops.rup(Cout, 16) * ops.rup(Cin, 16), device="cuda")
-            d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), 0, ops.dt_of(x), N, H, W, x.shape[3], Cin, Ho, Wo, dy.shape[3], Cout,
+            d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), 0, 0, ops.dt_of(x), N, H, W, x.shape[3], Cin, Ho, Wo, dy.shape[3], Cout,
                             k, k, -pad, -pad, s, 0, N, 0, 0, 0)
+            dwp = torch.zeros(L.wgrad_parts(d) * k * k * ops.rup(Cout, 16) * ops.rup(Cin, 16), device="cuda")     # one slice per pixel split
+            d.dwp = dwp.data_ptr()
             t = timeit(lambda: L.call(L.lib.mfc_conv2d_wgrad, d))
             line += f" | wgrad {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF"
         print(line, flush=True)

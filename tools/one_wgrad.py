@@ -11,9 +11,10 @@ pad = k // 2
 Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
 x = torch.randn(N, H, W, ops.rup(Cin, 8), device="cuda").to(dt)
 dy = torch.randn(N, Ho, Wo, ops.rup(Cout, 8), device="cuda").to(dt)
-dwp = torch.zeros(k * k * ops.rup(Cout, 16) * ops.rup(Cin, 16), device="cuda")
-d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), dwp.data_ptr(), 0, ops.dt_of(x), N, H, W, x.shape[3], Cin, Ho, Wo, dy.shape[3], Cout,
+d = L.WgradDesc(x.data_ptr(), dy.data_ptr(), 0, 0, ops.dt_of(x), N, H, W, x.shape[3], Cin, Ho, Wo, dy.shape[3], Cout,
                 k, k, -pad, -pad, s, 0, N, 0, 0, 0)
+dwp = torch.zeros(L.wgrad_parts(d) * k * k * ops.rup(Cout, 16) * ops.rup(Cin, 16), device="cuda")     # one slice per pixel split
+d.dwp = dwp.data_ptr()
 for _ in range(iters):
     L.call(L.lib.mfc_conv2d_wgrad, d)
 torch.cuda.synchronize()
