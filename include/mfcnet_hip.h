@@ -200,7 +200,10 @@ int mfc_combine_fwd(const mfc_combine_desc* d, void* stream);
 /* ------------------------------------------------------------------------------------
  * BatchNorm / ReLU backward (precedent: inplace_abn_cuda.cu:174-292 edz_eydz + backward).
  *   m     = mask (mode 0: 1; mode 1: mask_src > 0; mode 2: y*scale+shift > 0)
- *   reduce:   bstats[r][g][0][c] += sum g*m ;  bstats[r][g][1][c] += sum g*m*yhat
+ *   reduce:   bstats[r][g][0][c] += sum g*m ;  bstats[r][g][1][c] += sum g*m*yhat ;
+ *             if dy.ptr is set, the masked gradient is also written out: dy (+)= g*m (`accumulate`) -- the residual /
+ *             identity branch of the same sum receives exactly g*m, so one pass serves both (and later passes can
+ *             read g*m back instead of g and the mask)
  *   finalize: c1 = mean(g*m), c2 = mean(g*m*yhat)  (0 in eval mode);
  *             dgamma[c] = sum_g sum g*m*yhat, dbeta[c] = sum_g sum g*m
  *   apply:    dy = scale * (g*m - c1 - yhat*c2)
@@ -210,7 +213,7 @@ typedef struct {
     mfc_view g;              /* gradient wrt the BN output (post-activation if mask) */
     mfc_view y;              /* conv output (pre-BN); y.coef = this BN's coefficient block */
     mfc_view mask;           /* mode 1: tensor whose sign gives the ReLU mask */
-    mfc_view dy;             /* apply: destination (may alias g) */
+    mfc_view dy;             /* apply: destination (may alias g); reduce: optional g*m output */
     float* bstats;           /* [R][G][2][Cp] */
     const float* bcoef;      /* [G][2][Cp] c1, c2 (apply) */
     int32_t mask_mode, dtype, N, C, images_per_group, accumulate;

@@ -263,6 +263,16 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
                 apply_mask<T>(d, mr[u], yv, cf, gm);
 #pragma unroll
                 for (int e = 0; e < E; ++e) { s1[e] += gm[e]; s2[e] += gm[e] * (yv[e] - mean[e]) * rstd[e]; }
+                if (d.dy.ptr) {          // masked gradient for the identity branch of the same sum
+                    char* o = (char*)d.dy.ptr + ((size_t)(gbase + pp + (long)u * PPI) * d.dy.Cp + d.dy.c_off + gi * E) * sizeof(T);
+                    if (d.accumulate) {
+                        float old[E];
+                        Gran<T>::unpack(*(const uint4*)o, old);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) gm[e] += old[e];
+                    }
+                    *(uint4*)o = Gran<T>::pack(gm);
+                }
             }
         }
     }
@@ -302,6 +312,7 @@ static int bnbwd_check(const mfc_bnbwd_desc* d, int& E) {
 extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
     int E; int rc = bnbwd_check(d, E); if (rc < 0) return rc;
     if (!d->bstats) return MFC_ERR_INVALID_ARG;
+    if (d->dy.ptr && (!view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W)) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     if (Cg > 256) return MFC_ERR_UNSUPPORTED;
     const int PPI = 256 / Cg;

@@ -409,18 +409,28 @@ class Plan:
         return self.conv(o, p + "last_layer.3.weight", self.nc, 1, 1, True).t
 
     # ------------------------------------------------------------------ backward program
-    def _bn_backward(self, bn: BN, y: Ten, g_view: L.View, mask_mode, mask_view, dy_view: L.View, C):
-        d = L.BnBwdDesc()
-        d.g, d.y, d.dy = g_view, self.view(y, bn), dy_view
-        if mask_view is not None:
-            d.mask = mask_view
-        d.bstats, d.bcoef = bn.bstats, bn.bcoef
-        d.mask_mode, d.dtype, d.N, d.C, d.images_per_group, d.accumulate = mask_mode, self.dtype, y.N, C, y.ipg, 0
-        self.bwd.append((L.OP_BNBWD_REDUCE, d))
+    def _bn_backward(self, bn: BN, y: Ten, g_view: L.View, mask_mode, mask_view, dy_view: L.View, C, gm_view=None, gm_acc=0):
+        """reduce -> finalize -> apply.  With gm_view the reduce pass also writes the masked gradient g*m there (the
+        identity branch of the same sum, += if gm_acc); when it was a plain write, the apply pass reads g*m back from it
+        instead of g and the mask (one tensor less)."""
+        def desc(g, mode, mask, dy, acc):
+            d = L.BnBwdDesc()
+            d.g, d.y = g, self.view(y, bn)
+            if dy is not None:
+                d.dy = dy
+            if mask is not None:
+                d.mask = mask
+            d.bstats, d.bcoef = bn.bstats, bn.bcoef
+            d.mask_mode, d.dtype, d.N, d.C, d.images_per_group, d.accumulate = mode, self.dtype, y.N, C, y.ipg, acc
+            return d
+        self.bwd.append((L.OP_BNBWD_REDUCE, desc(g_view, mask_mode, mask_view, gm_view, gm_acc)))
         self.bwd.append((L.OP_BNBWD_FIN, L.BnBwdFinDesc(bn.bstats, bn.bcoef, self.gptr(bn.name + ".weight"),
                                                         self.gptr(bn.name + ".bias"), bn.C, bn.Cp, bn.G,
                                                         1 if bn.training else 0, bn.count)))
-        self.bwd.append((L.OP_BNBWD_APPLY, d))
+        if gm_view is not None and not gm_acc:
+            self.bwd.append((L.OP_BNBWD_APPLY, desc(gm_view, 0, None, dy_view, 0)))
+        else:
+            self.bwd.append((L.OP_BNBWD_APPLY, desc(g_view, mask_mode, mask_view, dy_view, 0)))
 
     def _emit_backward(self):
         E, Cs = self.E, None
@@ -456,27 +466,51 @@ class Plan:
                 assert out.grad_init, out.name
                 gv = L.View(g.ptr, 0, g.H, g.W, g.Cp, out_c_off)
                 mv = L.View(out.ptr, 0, out.H, out.W, out.Cp, out_c_off) if relu else None
-                for tm in terms:
+                mode = 1 if relu else 0
+                same = lambda tm: tm.t.H == out.H and tm.t.W == out.W
+                # The identity term of a ReLU'd sum receives exactly g*m.  If its gradient buffer is still unwritten, let the
+                # BN-backward reduce pass of a same-resolution BN term write it (no separate mask pass), and let every other
+                # term read g*m back from there instead of g and the mask.
+                idt = next((tm for tm in terms if relu and tm.bn is None and same(tm) and tm.t.needs_grad and not tm.t.grad_init), None)
+                fuse_bn = next((tm for tm in terms if tm.bn is not None and same(tm) and tm.t.needs_grad), None) if idt else None
+                order = list(terms)
+                if idt is not None:          # materialise g*m first
+                    first = fuse_bn if fuse_bn is not None else idt
+                    order.remove(first)
+                    order.insert(0, first)
+                    if fuse_bn is not None:
+                        order.remove(idt)
+                gmv = None
+                for tm in order:
                     s = tm.t
                     if not s.needs_grad:
                         continue
                     sg = self.grad_of(s)
-                    same = (s.H == out.H and s.W == out.W)
-                    if tm.bn is None or not same:
+                    g_in, m_in, md_in = (gmv, None, 0) if gmv is not None else (gv, mv, mode)
+                    if tm.bn is None or not same(tm):
                         md = L.MaskAddDesc()
-                        md.g, md.dst = gv, L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
-                        if mv is not None:
-                            md.mask = mv
+                        md.g, md.dst = g_in, L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
+                        if m_in is not None:
+                            md.mask = m_in
                         acc = 1 if (s.grad_init and tm.bn is None) else 0
-                        md.mask_mode, md.dtype, md.N, md.C, md.accumulate = (1 if relu else 0), self.dtype, out.N, Cs, acc
+                        md.mask_mode, md.dtype, md.N, md.C, md.accumulate = md_in, self.dtype, out.N, Cs, acc
                         self.bwd.append((L.OP_MASK_ADD, md))
                         s.grad_init = True
+                        if tm is idt:
+                            gmv = L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
                         if tm.bn is not None:       # up-sampled BN term: BN backward at the low resolution, in place
                             sv = L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
                             self._bn_backward(tm.bn, s, sv, 0, None, sv, Cs)
                     else:
                         assert not s.grad_init, s.name
-                        self._bn_backward(tm.bn, s, gv, 1 if relu else 0, mv, L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off), Cs)
+                        dyv = L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
+                        if tm is fuse_bn:
+                            ig = self.grad_of(idt.t)
+                            gmv = L.View(ig.ptr, 0, ig.H, ig.W, ig.Cp, idt.c_off)
+                            self._bn_backward(tm.bn, s, gv, mode, mv, dyv, Cs, gm_view=gmv, gm_acc=0)
+                            idt.t.grad_init = True
+                        else:
+                            self._bn_backward(tm.bn, s, g_in, md_in, m_in, dyv, Cs)
                         s.grad_init = True
             elif kind == "conv":
                 _, x, y, ci, bn = op

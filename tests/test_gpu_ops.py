@@ -248,13 +248,30 @@ def test_bn_backward(M, dtype, mode):
         d.mask = ops.view(ta)
     d.bstats, d.bcoef = bst.data_ptr(), bco.data_ptr()
     d.mask_mode, d.dtype, d.N, d.C, d.images_per_group, d.accumulate = mode, ops.dt_of(ty), N, Cc, ipg, 0
-    L.call(L.lib.mfc_bnbwd_reduce, d)
+    tol = TOL[dtype] * 2
+    # the reduce pass optionally writes the masked gradient g*m (= the residual branch's gradient): plain and accumulating
+    gm = torch.full_like(ty, 7.0)
+    gm1 = torch.ones_like(ty)
+    dr = L.BnBwdDesc.from_buffer_copy(d)
+    dr.dy, dr.accumulate = ops.view(gm), 0
+    L.call(L.lib.mfc_bnbwd_reduce, dr)
+    gm_ref = ga * (a.detach() > 0) if mode != 0 else ga
+    assert relerr(ops.to_nchw(gm, Cc).cpu(), gm_ref) < tol
+    bst.zero_()
+    dr.dy, dr.accumulate = ops.view(gm1), 1
+    L.call(L.lib.mfc_bnbwd_reduce, dr)
+    assert relerr(ops.to_nchw(gm1, Cc).cpu() - 1.0, gm_ref) < tol
     f = L.BnBwdFinDesc(bst.data_ptr(), bco.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), Cc, Cc, G, 1, float(ipg * H * W))
     L.call(L.lib.mfc_bnbwd_finalize, f)
     L.call(L.lib.mfc_bnbwd_apply, d)
-    tol = TOL[dtype] * 2
     assert relerr(ops.to_nchw(dy, Cc).cpu(), y.grad) < tol
     assert relerr(dgam.cpu(), gamma.grad) < tol and relerr(dbet.cpu(), beta.grad) < tol
+    # ... and the apply pass may read g*m back instead of g and the mask
+    dy2 = torch.zeros_like(ty)
+    da = L.BnBwdDesc.from_buffer_copy(d)
+    da.g, da.dy, da.mask_mode = ops.view(gm), ops.view(dy2), 0
+    L.call(L.lib.mfc_bnbwd_apply, da)
+    assert relerr(ops.to_nchw(dy2, Cc).cpu(), y.grad) < tol
 
 
 @pytest.mark.parametrize("dtype", DT)
