@@ -103,10 +103,10 @@ def main():
     def step():
         opt.zero_grad()
         out = model(frames)
-        loss, _ = mfc.mfc_loss(out, mask)
+        loss, _ = mfc.mfc_loss(out, mask, global_batch=True)      # loss over the global batch (all-reduce of 26 sums), as the reference
         loss.backward()
         if world > 1:
-            allreduce_grads(model, world)
+            allreduce_grads(model, world, average=False)             # ... so the ranks' gradients add up
         opt.step()
         return loss
 

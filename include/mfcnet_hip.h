@@ -275,8 +275,13 @@ int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, void* strea
 
 /* ------------------------------------------------------------------------------------
  * Loss: F.log_softmax(dim=1) + class-weighted NLL + soft-Jaccard, forward and gradient
- * wrt logits (src/engine.py:65-66, src/loss.py:31-63).  acc: fp32[16] zeroed by the call:
- *   [0] sum w_t*(-logp_t)  [1] sum w_t   [2+c] I_c  [7+c] sum p_c  [12+c]... see loss.hip
+ * wrt logits (src/engine.py:65-66, src/loss.py:31-63).  acc: fp32[32]:
+ *   [0] sum w_t*(-logp_t)  [1] sum w_t  [2+c] I_c = sum p_c*[t==c]  [10+c] sum p_c  [18+c] sum [t==c]   (c < 8)
+ *   [26] nll  [27] soft-jaccard  [28] w_nll*nll + w_jac*jaccard
+ * mfc_loss_fwd = mfc_loss_partial (zeroes acc, accumulates [0..25] over this call's B clips) + mfc_loss_finalize
+ * ([26..28] from the sums).  Data-parallel ranks all-reduce (SUM) acc[0..25] between the two calls: the reference
+ * evaluates both terms over the whole gathered batch (engine.py:64-66 runs after DataParallel's gather; the Jaccard
+ * I/U sums span the batch, loss.py:57-58).  mfc_loss_bwd reads the (global) sums from acc.
  * ------------------------------------------------------------------------------------ */
 typedef struct {
     const float* logits;     /* NCHW fp32 [B, nc, H, W] */
@@ -287,8 +292,20 @@ typedef struct {
     int32_t B, nc, H, W;
     float w_nll, w_jac, grad_scale;
 } mfc_loss_desc;
-int mfc_loss_fwd(const mfc_loss_desc* d, void* stream);   /* acc[16..19] = nll, jaccard, total */
+int mfc_loss_fwd(const mfc_loss_desc* d, void* stream);
+int mfc_loss_partial(const mfc_loss_desc* d, void* stream);
+int mfc_loss_finalize(const mfc_loss_desc* d, void* stream);
 int mfc_loss_bwd(const mfc_loss_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Validation metrics on device.  Replaces `outputs.data.cpu().numpy().argmax(axis=1)` +
+ * calculate_confusion_matrix_from_arrays (src/metrics.py:6-8,60-67) of every validation batch
+ * (src/engine.py:139): per-sample confusion counts conf[b][truth][prediction] (int64, overwritten);
+ * argmax takes the FIRST maximum like numpy.  IoU (first sample only -- get_jaccard's `[0]`,
+ * metrics.py:41-45) and Dice (whole batch, :47-48) follow from the counts on the host.
+ * ------------------------------------------------------------------------------------ */
+int mfc_confusion_counts(const float* outputs /* NCHW fp32 [B, nc, H, W] */, const int64_t* target /* [B, H, W] */,
+                         int64_t* conf /* [B][nc][nc] */, int32_t B, int32_t nc, int32_t H, int32_t W, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Adam over flat fp32 arenas (torch.optim.Adam semantics, no weight decay, no amsgrad;

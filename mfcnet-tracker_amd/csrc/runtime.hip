@@ -61,16 +61,27 @@ static int loss_check(const mfc_loss_desc* d) {
     return MFC_OK;
 }
 
-extern "C" int mfc_loss_fwd(const mfc_loss_desc* d, void* stream) {
+extern "C" int mfc_loss_partial(const mfc_loss_desc* d, void* stream) {
     int rc = loss_check(d); if (rc < 0) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(d->acc, 0, 32 * sizeof(float), st) != hipSuccess) return MFC_ERR_LAUNCH;
     const long total = (long)d->B * d->H * d->W;
     long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(loss_fwd_kernel, dim3((int)blocks), dim3(256), 0, st, *d, total);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, *d);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
+}
+
+extern "C" int mfc_loss_finalize(const mfc_loss_desc* d, void* stream) {
+    if (!d || !d->acc || d->nc < 2 || d->nc > 8) return MFC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *d);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+extern "C" int mfc_loss_fwd(const mfc_loss_desc* d, void* stream) {
+    const int rc = mfc_loss_partial(d, stream);
+    return rc < 0 ? rc : mfc_loss_finalize(d, stream);
 }
 
 __global__ __launch_bounds__(256) void loss_bwd_kernel(mfc_loss_desc d, long total) {
@@ -113,6 +124,41 @@ extern "C" int mfc_loss_bwd(const mfc_loss_desc* d, void* stream) {
     const long total = (long)d->B * d->H * d->W;
     long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, *d, total);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// ------------------------------------------------------------------ validation metrics
+// grid (blocks per sample, B): LDS histogram of (truth, argmax) pairs, then one 64-bit atomic per non-empty bin
+__global__ __launch_bounds__(256) void confusion_kernel(const float* out, const int64_t* target, unsigned long long* conf,
+                                                        int nc, long HW) {
+    __shared__ unsigned hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const float* o = out + (size_t)b * nc * HW;
+    const int64_t* t = target + (size_t)b * HW;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < HW; r += (long)gridDim.x * 256) {
+        float best = o[r]; int arg = 0;
+        for (int c = 1; c < nc; ++c) {
+            const float v = o[(size_t)c * HW + r];
+            if (v > best) { best = v; arg = c; }          // strict: the first maximum wins (numpy.argmax)
+        }
+        const int tt = (int)t[r];
+        if (tt >= 0 && tt < nc) atomicAdd(&hist[tt * nc + arg], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < nc * nc && hist[threadIdx.x]) atomicAdd(conf + (size_t)b * nc * nc + threadIdx.x, (unsigned long long)hist[threadIdx.x]);
+}
+
+extern "C" int mfc_confusion_counts(const float* outputs, const int64_t* target, int64_t* conf, int32_t B, int32_t nc, int32_t H,
+                                    int32_t W, void* stream) {
+    if (!outputs || !target || !conf || B <= 0 || nc < 2 || nc > 8 || H <= 0 || W <= 0) return MFC_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(conf, 0, (size_t)B * nc * nc * sizeof(int64_t), st) != hipSuccess) return MFC_ERR_LAUNCH;
+    const long HW = (long)H * W;
+    long bx = (HW + 255) / 256; if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(confusion_kernel, dim3((int)bx, B), dim3(256), 0, st, outputs, target, (unsigned long long*)conf, nc, HW);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

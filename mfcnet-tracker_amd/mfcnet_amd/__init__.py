@@ -7,3 +7,6 @@ from ._lib import BF16, F32, MfcError, lib  # noqa: F401  (importing loads libmf
 from .model import HRNetMultiBasic, HRNetMultiLarge, get_multiframe_segmentation_model  # noqa: F401
 from .optim import FlatAdam  # noqa: F401
 from .loss import mfc_loss  # noqa: F401
+from .metrics import confusion_counts, get_metrics  # noqa: F401
+from .checkpoint import load_base_model_weights, load_model_weights, save_model  # noqa: F401
+from .engine import eval_step, train_step  # noqa: F401

@@ -12,8 +12,21 @@ import torch
 import torch.distributed as dist
 
 
-def allreduce_grads(model, world_size=None, bucket_mb: int = 64, group=None):
-    """Average `model._G` (every parameter's .grad is a view of it) across ranks, in place."""
+LOSS_SUMS = 26      # acc[0:26] of mfc_loss_partial are the batch sums; acc[26:29] are derived by mfc_loss_finalize
+
+
+def allreduce_loss_sums(acc: torch.Tensor, group=None):
+    """SUM the loss partial sums (weighted NLL numerator / denominator, per-class I, sum p, sum [t==c]) over the ranks:
+    the reference computes both loss terms on the gathered batch (src/engine.py:64-66, src/loss.py:57-58)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(acc[:LOSS_SUMS], op=dist.ReduceOp.SUM, group=group)
+    return acc
+
+
+def allreduce_grads(model, world_size=None, bucket_mb: int = 64, group=None, average=True):
+    """Reduce `model._G` (every parameter's .grad is a view of it) across ranks, in place.
+    average=True: mean over ranks (per-rank losses).  average=False: sum (loss evaluated over the global batch with
+    mfc_loss(global_batch=True), whose logit gradients already carry the global normalisers)."""
     if not dist.is_initialized():
         return
     world_size = world_size or dist.get_world_size(group)
@@ -22,14 +35,14 @@ def allreduce_grads(model, world_size=None, bucket_mb: int = 64, group=None):
     g = model._G
     n = g.numel()
     step = max(1, bucket_mb * (1 << 20) // 4)
-    avg = dist.get_backend(group) == "nccl"
+    avg = average and dist.get_backend(group) == "nccl"
     works = []
     for a in range(0, n, step):
         sl = g[a:min(n, a + step)]
         works.append(dist.all_reduce(sl, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True))
     for w in works:
         w.wait()
-    if not avg:
+    if average and not avg:
         g.div_(world_size)
 
 

@@ -3,6 +3,11 @@
 `mfc_loss(logits, target, ...)` returns (total_loss_tensor, acc) where `acc[26:29]` holds
 (nll, soft_jaccard, total) as device scalars -- no `.item()` host sync is needed inside the step
 (the reference syncs three times per step).
+
+Data parallel (`global_batch=True` with an initialised process group): the 26 partial sums are all-reduced between the
+partial and the finalize kernels, so both terms are evaluated over the WHOLE batch exactly as the reference does after
+DataParallel's gather (engine.py:64-66; the Jaccard I/U sums span the batch, loss.py:57-58).  The logit gradients then
+carry the global normalisers, and the parameter gradients of the ranks must be SUMMED (dist.allreduce_grads(average=False)).
 """
 from __future__ import annotations
 
@@ -15,13 +20,19 @@ DEFAULT_CLASS_WEIGHTS = (1.0, 1000.0, 1000.0, 1000.0, 1000.0)
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, class_w, w_nll, w_jac):
+    def forward(ctx, logits, target, class_w, w_nll, w_jac, group):
         logits = logits.contiguous().float()
         target = target.contiguous()
         B, nc, H, W = logits.shape
         acc = torch.empty(32, dtype=torch.float32, device=logits.device)
         d = L.LossDesc(logits.data_ptr(), target.data_ptr(), class_w.data_ptr(), acc.data_ptr(), 0, B, nc, H, W, w_nll, w_jac, 1.0)
-        L.call(L.lib.mfc_loss_fwd, d)
+        if group is None:
+            L.call(L.lib.mfc_loss_fwd, d)
+        else:
+            from .dist import allreduce_loss_sums
+            L.call(L.lib.mfc_loss_partial, d)
+            allreduce_loss_sums(acc, group if group is not True else None)
+            L.call(L.lib.mfc_loss_finalize, d)
         ctx.save_for_backward(logits, target, class_w, acc)
         ctx.w = (w_nll, w_jac)
         ctx.mark_non_differentiable(acc)
@@ -35,13 +46,19 @@ class _LossFn(torch.autograd.Function):
         d = L.LossDesc(logits.data_ptr(), target.data_ptr(), class_w.data_ptr(), acc.data_ptr(), dl.data_ptr(), B, nc, H, W,
                        ctx.w[0], ctx.w[1], 1.0)
         L.call(L.lib.mfc_loss_bwd, d)
-        return dl * gtot, None, None, None, None
+        return dl * gtot, None, None, None, None, None
 
 
-def mfc_loss(logits, target, class_weights=DEFAULT_CLASS_WEIGHTS, w_nll=0.7, w_jac=0.3):
+def mfc_loss(logits, target, class_weights=DEFAULT_CLASS_WEIGHTS, w_nll=0.7, w_jac=0.3, global_batch=False, group=None):
+    """`global_batch=True`: evaluate the loss over all ranks' clips (see module docstring); `group` = process group."""
     if not logits.is_cuda:
         raise L.MfcError("mfc_loss runs on the GPU only")
     cw = torch.as_tensor(class_weights, dtype=torch.float32, device=logits.device)
     if target.dtype != torch.int64:
         target = target.long()
-    return _LossFn.apply(logits, target, cw, float(w_nll), float(w_jac))
+    g = None
+    if global_batch:
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            g = group if group is not None else True
+    return _LossFn.apply(logits, target, cw, float(w_nll), float(w_jac), g)

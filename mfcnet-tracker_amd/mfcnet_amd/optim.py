@@ -40,3 +40,17 @@ class FlatAdam:
             L.check(L.lib.mfc_adam_step(mdl._P.data_ptr() + 4 * a, mdl._G.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
                                         self.v.data_ptr() + 4 * a, n, self.lrs[name], self.betas[0], self.betas[1], self.eps,
                                         self.step_count, grad_scale, st), "mfc_adam_step")
+
+    # ---- checkpointing (utils/model_utils.py:6-12 stores optimizer.state_dict() next to the model's) ----
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.m.detach().cpu().clone(), "exp_avg_sq": self.v.detach().cpu().clone(),
+                "lrs": dict(self.lrs), "betas": tuple(self.betas), "eps": self.eps, "layout": "flat-arena-v1"}
+
+    def load_state_dict(self, sd):
+        if sd.get("layout") != "flat-arena-v1" or sd["exp_avg"].numel() != self.m.numel():
+            raise L.MfcError("optimizer state does not belong to a FlatAdam of this model")
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        self.lrs.update(sd["lrs"])
+        self.betas, self.eps = tuple(sd["betas"]), float(sd["eps"])

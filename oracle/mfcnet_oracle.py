@@ -457,6 +457,103 @@ def total_loss(logits, target, num_classes=5, loss_fns=("nll", "soft_jaccard"), 
     return tot, parts
 
 
+def loss_partial_sums(logits, target, class_weights=DEFAULT_CLASS_WEIGHTS):
+    """The 26 batch sums both loss terms are made of (layout of the build's `acc` block, include/mfcnet_hip.h):
+    [0] sum w_t*(-logp_t), [1] sum w_t (loss.py:31-43, weighted-mean NLL); [2+c] I_c = sum p_c*[t==c], [10+c] sum p_c,
+    [18+c] sum [t==c] (loss.py:45-63).  Sums over disjoint parts of a batch add up to the sums of the whole batch, which is
+    what a data-parallel run all-reduces (the reference evaluates the loss on the gathered batch, engine.py:64-66)."""
+    logp = F.log_softmax(logits.double(), dim=1)
+    nc = logits.shape[1]
+    cw = torch.as_tensor(class_weights, dtype=torch.float64)
+    acc = torch.zeros(32, dtype=torch.float64)
+    wt = cw[target]
+    acc[0] = -(wt * logp.gather(1, target[:, None]).squeeze(1)).sum()
+    acc[1] = wt.sum()
+    for c in range(1, nc):
+        p = logp[:, c].exp()
+        tc = (target == c).double()
+        acc[2 + c], acc[10 + c], acc[18 + c] = (p * tc).sum(), p.sum(), tc.sum()
+    return acc
+
+
+def loss_from_sums(acc, num_classes=5, loss_wts=(0.7, 0.3)):
+    """(nll, soft_jaccard, total) from the batch sums: loss.py:31-43 (weighted mean) and loss.py:45-63
+    (-log((I+eps)/(U+eps)), U = sum p + sum [t==c] - I, summed over classes 1.. and divided by num_classes)."""
+    eps = 1e-15
+    nll = acc[0] / acc[1]
+    jac = 0.0
+    for c in range(1, num_classes):
+        I = acc[2 + c]
+        U = acc[10 + c] + acc[18 + c] - I
+        jac = jac - torch.log((I + eps) / (U + eps))
+    jac = jac / num_classes
+    return nll, jac, loss_wts[0] * nll + loss_wts[1] * jac
+
+
+# ------------------------------------------------------------------------------------------
+# validation metrics (src/metrics.py), numpy restatement
+# ------------------------------------------------------------------------------------------
+def metric_case_inputs(B, nc, H, W, seed, scale):
+    """Deterministic (logits fp32 [B,nc,H,W], mask int64 [B,H,W]) of a metrics fixture.  scale == 0 gives logits quantised
+    to {0, 0.5, 1} (many exact ties); the case named `empty` (seed 104) uses only classes 0..2 in the mask."""
+    g = torch.Generator().manual_seed(int(seed))
+    if scale == 0:
+        logits = torch.randint(0, 3, (B, nc, H, W), generator=g).float() * 0.5
+    else:
+        logits = torch.randn(B, nc, H, W, generator=g) * float(scale)
+    hi = 3 if int(seed) == 104 else nc
+    mask = torch.randint(0, hi, (B, H, W), generator=g)
+    return logits, mask
+
+
+def confusion_per_sample(pred_classes, target_classes, num_classes):
+    """[B][truth][prediction] counts; summed over B it is metrics.py:60-67 (histogramdd over (ground_truth, prediction))."""
+    import numpy as np
+    p = np.asarray(pred_classes).reshape(len(pred_classes), -1)
+    t = np.asarray(target_classes).reshape(len(target_classes), -1)
+    out = np.zeros((p.shape[0], num_classes, num_classes), dtype=np.int64)
+    for b in range(p.shape[0]):
+        np.add.at(out[b], (t[b], p[b]), 1)
+    return out
+
+
+def metrics_from_confusion(conf, metric_fns=("iou", "dice")):
+    """metrics.py:4-39 from the per-sample confusion counts, background (class 0) excluded.
+    iou_c follows get_jaccard (metrics.py:41-45): the per-sample ratio ... `[0]`, i.e. of the FIRST sample of the batch only;
+    dice_c follows get_dice (metrics.py:47-48): sums over the whole batch.  Returns (values per class, metric_dict)."""
+    import numpy as np
+    conf = np.asarray(conf, dtype=np.float64)
+    nc = conf.shape[1]
+    eps = 1e-15
+    vals, md = [], {}
+    for fn in metric_fns:
+        per = []
+        if fn == "iou":
+            c0 = conf[0]
+            for c in range(1, nc):
+                inter, true, pred = c0[c, c], c0[c, :].sum(), c0[:, c].sum()
+                per.append((inter + eps) / (true + pred - inter + eps))
+        elif fn == "dice":
+            call = conf.sum(axis=0)
+            for c in range(1, nc):
+                inter, true, pred = call[c, c], call[c, :].sum(), call[:, c].sum()
+                per.append((2 * inter + eps) / (true + pred + eps))
+        elif fn == "jaccard":
+            raise NotImplementedError
+        else:
+            raise ValueError(f"Metric function {fn} not implemented")
+        vals.append(per)
+        md["metric_" + fn] = float(np.mean(per))
+    return vals, md
+
+
+def get_metrics(outputs, targets, metric_fns, num_classes):
+    """metrics.py:4-39: argmax over the class axis (first maximum wins, numpy.argmax), then the per-class ratios."""
+    pred = outputs.detach().cpu().numpy().argmax(axis=1)
+    conf = confusion_per_sample(pred, targets.detach().cpu().numpy(), num_classes)
+    return metrics_from_confusion(conf, metric_fns)
+
+
 def make_adam(net: Net, lr: float = 1e-4, load_wts_base_model: bool = False):
     """scripts/train_multiframe_detection.py:128-151: two groups, base lr/T (or lr/(100T)), head lr."""
     base_lr = lr / (100.0 * net.T) if load_wts_base_model else lr / net.T

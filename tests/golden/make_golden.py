@@ -151,10 +151,46 @@ def run_case(mf, ref_loss, case):
     print(name, "ok", tuple(y.shape), {k: float(v) for k, v in out.items() if k.startswith("loss_")})
 
 
+METRIC_CASES = [            # (name, B, num_classes, H, W, seed, logit scale)
+    ("metrics_b3", 3, 5, 40, 56, 101, 2.0),
+    ("metrics_b1", 1, 5, 33, 47, 102, 1.0),
+    ("metrics_ties", 2, 5, 24, 32, 103, 0.0),      # scale 0 -> quantised logits with many ties: argmax takes the first maximum
+    ("metrics_empty", 2, 5, 16, 16, 104, 2.0),     # classes 3 and 4 absent from the masks: the epsilon terms decide
+]
+
+
+def metric_inputs(B, nc, H, W, seed, scale):
+    """Deterministic (logits, mask) of a metrics case; shared with the tests through oracle.metric_case_inputs."""
+    return O.metric_case_inputs(B, nc, H, W, seed, scale)
+
+
+def run_metric_case(case):
+    """Reference src/metrics.py::get_metrics (imported in place) on log-softmax outputs, as src/engine.py:137-139 calls it."""
+    name, B, nc, H, W, seed, scale = case
+    spec = importlib.util.spec_from_file_location("ref_metrics", f"{REF}/src/metrics.py")
+    rm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rm)
+    logits, mask = metric_inputs(B, nc, H, W, seed, scale)
+    out = torch.nn.functional.log_softmax(logits, dim=1)
+    vals, md = rm.get_metrics(out, mask, ["iou", "dice"], SimpleNamespace(num_classes=nc))
+    conf = rm.calculate_confusion_matrix_from_arrays(out.numpy().argmax(axis=1), mask.numpy(), nc)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), case=np.array([B, nc, H, W, seed], dtype=np.int64), scale=np.float64(scale),
+                        iou=np.array(vals[0], dtype=np.float64), dice=np.array(vals[1], dtype=np.float64),
+                        metric_iou=np.float64(md["metric_iou"]), metric_dice=np.float64(md["metric_dice"]),
+                        confusion=conf.astype(np.int64))
+    print(name, "ok", md)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    mf, ref_loss = import_reference()
     only = sys.argv[1:]
+    for c in METRIC_CASES:
+        if only and c[0] not in only:
+            continue
+        run_metric_case(c)
+    if only and all(o.startswith("metrics_") for o in only):
+        sys.exit(0)
+    mf, ref_loss = import_reference()
     for c in CASES:
         if only and c[0] not in only:
             continue

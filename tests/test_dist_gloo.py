@@ -40,3 +40,45 @@ def test_two_rank_gradient_allreduce_and_broadcast():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _loss_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mfcnet_amd.dist import allreduce_grads, allreduce_loss_sums, LOSS_SUMS
+    from oracle import mfcnet_oracle as O
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(4, 5, 12, 16, generator=g)
+    target = torch.randint(0, 5, (4, 12, 16), generator=g)
+    full, parts = O.total_loss(logits, target)                      # the reference's loss on the gathered batch
+    lo, hi = rank * 2, rank * 2 + 2                                 # this rank's clips
+    acc = O.loss_partial_sums(logits[lo:hi], target[lo:hi]).float()
+    acc[LOSS_SUMS:] = -1.0                                          # the derived slots must not be reduced
+    allreduce_loss_sums(acc)
+    nll, jac, tot = O.loss_from_sums(acc.double())
+    ok = abs(float(tot) - float(full)) < 1e-5 and abs(float(nll) - float(parts["loss_nll"])) < 1e-5
+    ok = ok and abs(float(jac) - float(parts["loss_soft_jaccard"])) < 1e-5 and bool((acc[LOSS_SUMS:] == -1.0).all())
+    # a loss normalised over the global batch wants the ranks' parameter gradients SUMMED
+    model = SimpleNamespace(_G=torch.full((1000,), float(rank + 1)))
+    allreduce_grads(model, world, average=False)
+    ok = ok and torch.allclose(model._G, torch.full((1000,), 3.0))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_global_batch_loss_sums():
+    """Splitting a batch over two ranks and all-reducing the 26 loss sums reproduces the loss of the whole batch
+    (the reference evaluates NLL and soft-Jaccard after DataParallel's gather, src/engine.py:64-66)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_loss_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -215,3 +215,35 @@ def test_full_gradients_vs_oracle(mfc, name):
         worst = max(worst, e)
         assert e < GRAD_RTOL, (p, e)
     print("worst full-tensor gradient rel-L2 vs oracle:", worst)
+
+
+def test_engine_steps_match_golden(mfc):
+    """mfcnet_amd.train_step / eval_step (the step bodies of src/engine.py:54-71 and :132-139) against the golden vectors:
+    one training step with FlatAdam reproduces the loss scalars and the post-Adam parameters; an eval batch reproduces the
+    logits, and its device metrics equal the reference formulae applied to the same output."""
+    from oracle import mfcnet_oracle as O
+    cfg, z = load_case("large_rgb_train")
+    m = build(mfc, cfg)
+    set_mode(m, "train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    opt = mfc.FlatAdam(m, lr=1e-4)
+    out, acc = mfc.train_step(m, opt, dev(frames), mask.cuda(), optflow=dev(flows), depth=dev(depths))
+    compare_logits(z, out.cpu().numpy(), ATOL)
+    a = acc.cpu()
+    assert abs(float(a[26]) - float(z["loss_nll"])) < 1e-4 and abs(float(a[28]) - float(z["loss_total"])) < 1e-4
+    named = dict(m.named_parameters())
+    for key in [f for f in z.files if f.startswith("paramsample/")]:
+        p = key.split("/", 1)[1]
+        lr = 1e-4 / cfg["T"] if p.startswith("base") else 1e-4
+        np.testing.assert_allclose(sample16(named[p]), z[key], rtol=0, atol=2.1 * lr, err_msg=p)
+    cfg, z = load_case("large_rgb_eval")
+    m = build(mfc, cfg)
+    m.eval()
+    frames, flows, depths, mask = case_inputs(cfg)
+    out, acc, vals, md = mfc.eval_step(m, dev(frames), mask.cuda(), ("iou", "dice"), 5)
+    compare_logits(z, out.cpu().numpy(), ATOL)
+    ref_vals, ref_md = O.get_metrics(out.cpu(), mask, ["iou", "dice"], 5)
+    assert np.allclose(vals[0], ref_vals[0], rtol=1e-12) and np.allclose(vals[1], ref_vals[1], rtol=1e-12)
+    assert abs(md["metric_dice"] - ref_md["metric_dice"]) < 1e-12
+    tot, parts = O.total_loss(out.cpu(), mask, 5)
+    assert abs(float(acc.cpu()[28]) - float(tot)) < 1e-4

@@ -399,6 +399,42 @@ def test_loss_fwd_bwd(M):
     assert relerr(lg.grad.cpu(), logits.grad) < 1e-4
 
 
+def test_loss_global_batch_split(M):
+    """Data-parallel form of the loss: two 'ranks' (two halves of the batch on one GPU) run mfc_loss_partial, their 26 sums
+    are added (what dist.allreduce_loss_sums does over RCCL), mfc_loss_finalize / mfc_loss_bwd then use the global sums.
+    Loss and logit gradients must equal the reference loss of the whole batch (src/engine.py:64-66 after the gather)."""
+    mfc, L, ops = M
+    from oracle import mfcnet_oracle as O
+    B, nc, H, W = 4, 5, 24, 40
+    g = torch.Generator().manual_seed(31)
+    logits = (torch.randn(B, nc, H, W, generator=g) * 2).requires_grad_(True)
+    target = torch.randint(0, nc, (B, H, W), generator=g)
+    tot, parts = O.total_loss(logits, target, nc)
+    tot.backward()
+    cw = torch.tensor(O.DEFAULT_CLASS_WEIGHTS, dtype=torch.float32, device="cuda")
+    halves, accs = [], []
+    for r in range(2):
+        lg = logits.detach()[2 * r:2 * r + 2].contiguous().cuda()
+        tg = target[2 * r:2 * r + 2].contiguous().cuda()
+        acc = torch.empty(32, device="cuda")
+        d = L.LossDesc(lg.data_ptr(), tg.data_ptr(), cw.data_ptr(), acc.data_ptr(), 0, 2, nc, H, W, 0.7, 0.3, 1.0)
+        L.call(L.lib.mfc_loss_partial, d)
+        halves.append((lg, tg)); accs.append(acc)
+    glob = accs[0] + accs[1]
+    ref_sums = O.loss_partial_sums(logits.detach(), target)
+    assert relerr(glob[:26].cpu().double(), ref_sums[:26]) < 1e-5
+    grads = []
+    for (lg, tg) in halves:
+        acc = glob.clone()
+        dl = torch.empty_like(lg)
+        d = L.LossDesc(lg.data_ptr(), tg.data_ptr(), cw.data_ptr(), acc.data_ptr(), dl.data_ptr(), 2, nc, H, W, 0.7, 0.3, 1.0)
+        L.call(L.lib.mfc_loss_finalize, d)
+        assert abs(float(acc[28]) - float(tot)) < 1e-5 and abs(float(acc[27]) - float(parts["loss_soft_jaccard"])) < 1e-5
+        L.call(L.lib.mfc_loss_bwd, d)
+        grads.append(dl.cpu())
+    assert relerr(torch.cat(grads), logits.grad) < 1e-4
+
+
 def test_adam_matches_torch(M):
     _, L, ops = M
     n = 10007
