@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--serial", action="store_true", help="one stream: no branch lanes / detached weight-gradient streams (for kernel profiles)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
@@ -115,6 +116,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.serial:
+        L.lib.mfc_set_flag(9, 0)
     for _ in range(args.warmup):
         step()
     sync()
@@ -125,11 +128,15 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - prof_steps:
+            # the profiled step runs every record on ONE stream: with the branch lanes / detached wgrad streams a launch shares
+            # the GPU with other kernels and its event-bracketed time would no longer be the kernel's own duration
+            L.lib.mfc_set_flag(9, 0)
             L.lib.mfc_prof_enable(1)
         loss = step()
     sync()
     dt = time.perf_counter() - t0
     L.lib.mfc_prof_enable(0)
+    L.lib.mfc_set_flag(9, 0 if args.serial else 3)
     prof = L.ProfResult()
     L.lib.mfc_prof_collect(C.byref(prof))
     if dist is not None:
@@ -170,7 +177,7 @@ def main():
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"MFCNet T={T} RGB-only (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, fwd+bwd+Adam "
                                       f"(BASELINE.json configs[2])", "width": args.width, "global_batch": world * B,
-                          "frames_per_clip": T, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5)},
+                          "frames_per_clip": T, "parallelism": f"dp{world}", "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width, T, H, W)

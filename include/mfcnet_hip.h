@@ -326,9 +326,14 @@ typedef enum {
     MFC_OP_NHWC2NCHW = 16
 } mfc_op_kind;
 
+#define MFC_LANE_ASYNC 0x100
 typedef struct {
     int32_t kind;
-    int32_t pad_;
+    int32_t lane;            /* 0: serial.  >= 1: member of a parallel section (a maximal run of such records): lane 1 runs on
+                              * the caller's stream, lanes 2..8 on side streams forked / joined with events; records of
+                              * different lanes of one section must be independent (e.g. the branches of one HRNet module).
+                              * | MFC_LANE_ASYNC: detached -- ordered after everything issued so far on its stream, runs on an
+                              * extra stream, joined before the next MFC_OP_UNPACK / at the program end (weight gradients) */
     union {
         mfc_conv_desc conv;
         mfc_wgrad_desc wgrad;
@@ -358,7 +363,8 @@ typedef struct { double ms[MFC_PROF_BUCKETS]; double flops[MFC_PROF_BUCKETS]; do
 int mfc_prof_enable(int on);
 int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded events, fills `out`, clears the log */
 
-/* tuning switches: id 1 = use ds_read_b64_tr_b16 in the bf16 wgrad kernel (default 1) */
+/* tuning switches: id 1 = use ds_read_b64_tr_b16 in the bf16 wgrad kernel (default 1); id 9 = honour record lanes
+ * (bit 0: parallel-section lanes, bit 1: detached records; default 3; 0 runs every record on the caller's stream); others are kernel-tuning knobs (see the sources) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

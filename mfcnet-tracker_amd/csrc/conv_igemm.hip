@@ -36,6 +36,7 @@ struct ConvK {
     int Yblocks, nunits, per_block;     // units = cout blocks (slow) x tiles (fast); units per workgroup
     int nslots, npieces, stage_bytes;   // weight slots per stage, 1-KiB DMA pieces per stage, bytes of one stage image
     int off_w0, off_w1, off_ktab, off_red;   // LDS offsets (bytes)
+    int ybfast;                              // unit order: 1 = cout block fastest (the Yblocks units of a pixel tile run back to back on one workgroup: the re-reads of the tile hit L2 instead of HBM)
     int ablate;                              // tuning only: 1 skip weight DMA, 2 skip patch staging, 4 skip output stores, 8 skip MFMAs
 };
 
@@ -117,11 +118,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     // unit = (cout block yb [slowest], image n, tile row, tile column [fastest]); tracked incrementally (no divisions per stage)
     struct UC { int yb, n, tyi, txi; };
     auto uc_init = [&](int u) {
-        UC r; r.yb = u / p.ntiles; int xt = u - r.yb * p.ntiles;
+        UC r; int xt;
+        if (p.ybfast) { xt = u / p.Yblocks; r.yb = u - xt * p.Yblocks; }
+        else { r.yb = u / p.ntiles; xt = u - r.yb * p.ntiles; }
         r.txi = xt % p.tilesX; xt /= p.tilesX; r.tyi = xt % p.tilesY; r.n = xt / p.tilesY;
         return r;
     };
     auto uc_next = [&](UC r) {
+        if (p.ybfast) {
+            if (++r.yb < p.Yblocks) return r;
+            r.yb = 0;
+            if (++r.txi == p.tilesX) { r.txi = 0; if (++r.tyi == p.tilesY) { r.tyi = 0; ++r.n; } }
+            return r;
+        }
         if (++r.txi == p.tilesX) { r.txi = 0; if (++r.tyi == p.tilesY) { r.tyi = 0; if (++r.n == p.N) { r.n = 0; ++r.yb; } } }
         return r;
     };
@@ -397,6 +406,8 @@ static int g_conv_force_mt = 0;      // tuning: mfc_set_flag(2, 2|4)
 int mfc_conv_set_force_mt(int v) { g_conv_force_mt = v; return 0; }
 static int g_conv_lds_kb = 80;       // LDS budget per workgroup (80 KiB -> 2 workgroups per CU); tuning: mfc_set_flag(6, kb)
 int mfc_conv_set_lds_kb(int v) { g_conv_lds_kb = v > 0 ? v : 80; return 0; }
+static int g_conv_ybfast = -1;        // -1 auto, 0 never, 1 always; tuning: mfc_set_flag(8, v)
+int mfc_conv_set_ybfast(int v) { g_conv_ybfast = v; return 0; }
 static int g_conv_ablate = 0;
 int mfc_conv_set_ablate(int v) { g_conv_ablate = v; return 0; }
 static int g_conv_grid = 512;        // persistent workgroups per launch (2 per CU); tuning: mfc_set_flag(4, n)
@@ -486,6 +497,10 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     k.ntiles = k.N * k.tilesY * k.tilesX;
     k.nunits = k.ntiles * k.Yblocks;
     k.ablate = g_conv_ablate;
+    {   // cout-block-fastest order when the Yblocks passes over the input would otherwise each stream it from HBM again
+        const double in_bytes = (double)k.N * k.Hin * k.Win * k.Cin_p * (d->dtype == MFC_BF16 ? 2.0 : 4.0);
+        k.ybfast = g_conv_ybfast >= 0 ? (g_conv_ybfast && k.Yblocks > 1) : (k.Yblocks > 1 && in_bytes * (k.Yblocks - 1) > 128e6);
+    }
     grid = g_conv_grid;
     if (grid > k.nunits) grid = k.nunits;
     k.per_block = ceil_div(k.nunits, grid);

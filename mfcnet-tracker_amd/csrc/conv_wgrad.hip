@@ -21,6 +21,8 @@ int mfc_conv_set_grid(int v);
 int mfc_conv_set_ablate(int v);
 static int g_wgrad_ablate = 0;
 int mfc_conv_set_lds_kb(int v);
+int mfc_conv_set_ybfast(int v);
+int mfc_set_lanes(int on);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
@@ -29,6 +31,8 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 5) return mfc_conv_set_ablate(value);
     if (id == 6) return mfc_conv_set_lds_kb(value);
     if (id == 7) { g_wgrad_ablate = value; return 0; }
+    if (id == 8) return mfc_conv_set_ybfast(value);
+    if (id == 9) return mfc_set_lanes(value);
     return MFC_ERR_INVALID_ARG;
 }
 
@@ -881,19 +885,34 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) 
     f.Co16 = ceil_div(d->Cout, 16) * 16; f.Ci16 = ceil_div(d->Cin, 16) * 16;
     const int co_t = f.Co16 / 16, ci_t = f.Ci16 / 16;
     const bool want_all = d->TB == 3 && d->TA == 3 && d->in_stride == 1 && co_t % 2 == 0 && ci_t % 2 == 0 && g_wgrad_ksplit != 3;
-    f.TH = 0; f.TW = 0;
-    if (want_all) choose_subtile(d->Hout, d->Wout, f.TH, f.TW, 64);     // 64 patch pixels x 4 granules = 4 pieces per lane
-    if (f.TH == 0) choose_subtile(d->Hout, d->Wout, f.TH, f.TW);
-    f.tilesY = ceil_div(d->Hout, f.TH); f.tilesX = ceil_div(d->Wout, f.TW);
-    f.ntiles = f.N * f.tilesY * f.tilesX;
     int WCO, WCI;
     if (d->TB == 11) { WCO = 1; WCI = ci_t >= 2 ? 2 : 1; }
     else { WCO = ceil_div(co_t, ceil_div(co_t, 3)); WCI = ceil_div(ci_t, ceil_div(ci_t, 3)); }
+    f.TH = 0; f.TW = 0;
+    if (want_all) choose_subtile(d->Hout, d->Wout, f.TH, f.TW, 64);     // 64 patch pixels x 4 granules = 4 pieces per lane
     // all-taps mode (3x3, 32x32-channel blocks): one workgroup accumulates all 9 taps, so the input rows are staged once
     // for the three tap rows instead of once per row (3x fewer staging instructions per MFMA)
-    const bool alltaps = want_all && ceil_div(((f.TH - 1) * f.s + 3) * ((f.TW - 1) * f.s + 3) * 4, 64) <= 4;     // staging must fit 4 pieces/lane
+    const bool alltaps = want_all && f.TH > 0 && ceil_div(((f.TH - 1) * f.s + 3) * ((f.TW - 1) * f.s + 3) * 4, 64) <= 4;     // staging must fit 4 pieces/lane
     if (alltaps) { WCO = 2; WCI = 2; }
     const int TAA = alltaps ? 3 : 1;
+    if (!alltaps) {
+        // one tap row per workgroup: pick the 32-pixel sub-tile whose staged input rows ((TH-1)*s+1) x ((TW-1)*s+TB) fit
+        // the 7 pieces per lane, preferring full tiles, then the smallest patch (strided convs want flat, wide tiles)
+        double best = -1; int bh = 0, bw = 0;
+        for (int tw = 1; tw <= 32 && tw <= d->Wout; ++tw) {
+            int th = 32 / tw; if (th > d->Hout) th = d->Hout; if (th < 1) continue;
+            const int phx = (th - 1) * f.s + 1, pw = (tw - 1) * f.s + d->TB;
+            if (pw > 255 || ceil_div(phx * pw * WCI * 2, 64) > 7) continue;
+            const double tiles = (double)ceil_div(d->Hout, th) * ceil_div(d->Wout, tw);
+            const double eff = (double)d->Hout * d->Wout / (tiles * 32.0);
+            const double score = eff - 0.0015 * (double)(phx * pw) / 32.0 * 4.0 + ((tw % 8 == 0) ? 0.01 : 0.0);
+            if (score > best) { best = score; bh = th; bw = tw; }
+        }
+        if (bh == 0) return MFC_ERR_UNSUPPORTED;
+        f.TH = bh; f.TW = bw;
+    }
+    f.tilesY = ceil_div(d->Hout, f.TH); f.tilesX = ceil_div(d->Wout, f.TW);
+    f.ntiles = f.N * f.tilesY * f.tilesX;
     f.co_blocks = ceil_div(co_t, WCO); f.ci_blocks = ceil_div(ci_t, WCI);
     f.gd = WCO * 2; f.gx = WCI * 2;
     f.PW = (f.TW - 1) * f.s + f.TB;

@@ -272,12 +272,95 @@ static int run_one(const mfc_op& o, void* stream) {
     }
 }
 
+// Lanes: records tagged lane >= 1 belong to a PARALLEL SECTION (a maximal run of such records, e.g. the independent
+// branches of one HighResolutionModule, hrnet.py:242-243): lane 1 stays on the caller's stream, lanes 2.. run on side
+// streams forked from it by an event and joined back at the next lane-0 record.  Records of different lanes in one section
+// must not touch each other's outputs (the plan guarantees it: nothing in the arenas is reused, and a branch only writes
+// its own tensors).  Under-filled launches of the low-resolution branches then share the GPU with the other branches.
+#define MFC_MAX_LANES 8
+#define MFC_ASYNC_STREAMS 2
+#define MFC_ASYNC_EVENTS 16
+struct LaneSet {
+    hipStream_t s[MFC_MAX_LANES + 1]; hipEvent_t fork, join[MFC_MAX_LANES + 1];
+    hipStream_t as[MFC_ASYNC_STREAMS]; hipEvent_t aev[MFC_ASYNC_EVENTS], ajoin[MFC_ASYNC_STREAMS];
+    bool ready;
+};
+static LaneSet g_lanes[16];
+static int g_lanes_on = 3;       // bit 0: parallel-section lanes, bit 1: detached (async) records
+int mfc_set_lanes(int on) { g_lanes_on = on; return 0; }
+
+static LaneSet* lanes_for_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    LaneSet* L = &g_lanes[dev];
+    if (!L->ready) {
+        for (int i = 2; i <= MFC_MAX_LANES; ++i)
+            if (hipStreamCreateWithFlags(&L->s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&L->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        for (int i = 2; i <= MFC_MAX_LANES; ++i)
+            if (hipEventCreateWithFlags(&L->join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        for (int i = 0; i < MFC_ASYNC_STREAMS; ++i) {
+            if (hipStreamCreateWithFlags(&L->as[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&L->ajoin[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        for (int i = 0; i < MFC_ASYNC_EVENTS; ++i)
+            if (hipEventCreateWithFlags(&L->aev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        L->ready = true;
+    }
+    return L;
+}
+
+// Detached records (lane bit MFC_LANE_ASYNC): work whose result nothing in the program reads before the next
+// MFC_OP_UNPACK / the program end -- the weight gradients.  Such a record waits (event) for everything issued so far on
+// the stream it would have run on, then runs on one of two extra streams, so the MFMA-bound wgrad launches overlap the
+// HBM-bound BatchNorm-backward sweeps and the data-gradient chain instead of sitting in it.
 extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
     if (!ops || n < 0) return MFC_ERR_INVALID_ARG;
+    hipStream_t mainst = (hipStream_t)stream;
+    LaneSet* L = nullptr;
+    bool in_par = false; unsigned used = 0;
+    unsigned aused = 0; int anext = 0, aevn = 0;
+    auto join = [&]() {
+        for (int l = 2; l <= MFC_MAX_LANES; ++l)
+            if (used & (1u << l)) { (void)hipEventRecord(L->join[l], L->s[l]); (void)hipStreamWaitEvent(mainst, L->join[l], 0); }
+        in_par = false; used = 0;
+    };
+    auto join_async = [&]() {
+        for (int a = 0; a < MFC_ASYNC_STREAMS; ++a)
+            if (aused & (1u << a)) { (void)hipEventRecord(L->ajoin[a], L->as[a]); (void)hipStreamWaitEvent(mainst, L->ajoin[a], 0); }
+        aused = 0;
+    };
     for (int i = 0; i < n; ++i) {
-        const int rc = run_one(ops[i], stream);
-        if (rc != MFC_OK) return -(1000 * (i + 1)) + rc;
+        const int lane = (g_lanes_on & 1) ? (ops[i].lane & 0xff) : 0;
+        const bool detached = (g_lanes_on & 2) && (ops[i].lane & MFC_LANE_ASYNC);
+        void* st = stream;
+        if (lane >= 2 && lane <= MFC_MAX_LANES) {
+            if (!L && !(L = lanes_for_device())) return -(1000 * (i + 1)) + MFC_ERR_LAUNCH;
+            if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; }
+            if (!(used & (1u << lane))) { (void)hipStreamWaitEvent(L->s[lane], L->fork, 0); used |= 1u << lane; }
+            st = (void*)L->s[lane];
+        } else if (lane == 1) {
+            if (!in_par) {
+                if (!L && !(L = lanes_for_device())) return -(1000 * (i + 1)) + MFC_ERR_LAUNCH;
+                (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0;
+            }
+        } else if (in_par) {
+            join();
+        }
+        if (ops[i].kind == MFC_OP_UNPACK && aused) join_async();       // (lane 0: the side lanes were joined just above)
+        if (detached) {
+            if (!L && !(L = lanes_for_device())) return -(1000 * (i + 1)) + MFC_ERR_LAUNCH;
+            hipEvent_t ev = L->aev[aevn]; aevn = (aevn + 1) % MFC_ASYNC_EVENTS;
+            (void)hipEventRecord(ev, (hipStream_t)st);
+            (void)hipStreamWaitEvent(L->as[anext], ev, 0);
+            st = (void*)L->as[anext];
+            aused |= 1u << anext; anext = (anext + 1) % MFC_ASYNC_STREAMS;
+        }
+        const int rc = run_one(ops[i], st);
+        if (rc != MFC_OK) { if (in_par) join(); if (aused) join_async(); return -(1000 * (i + 1)) + rc; }
     }
+    if (in_par) join();
+    if (aused) join_async();
     return MFC_OK;
 }
 

@@ -21,6 +21,7 @@ STAT_REPLICAS = 32
 
 # op kinds (mfc_op_kind)
 OP_CONV, OP_WGRAD, OP_BNFIN, OP_COMBINE, OP_BNBWD_REDUCE, OP_BNBWD_FIN, OP_BNBWD_APPLY, OP_MASK_ADD = range(1, 9)
+LANE_ASYNC = 0x100
 OP_HEAD_FWD, OP_HEAD_BWD, OP_BIAS_GRAD, OP_MEMSET, OP_PACK, OP_UNPACK, OP_NCHW2NHWC, OP_NHWC2NCHW = range(9, 17)
 
 i32, u64, f32, vp = C.c_int32, C.c_uint64, C.c_float, C.c_void_p
@@ -121,7 +122,7 @@ class OpUnion(C.Union):
 
 
 class Op(C.Structure):
-    _fields_ = [("kind", i32), ("pad_", i32), ("u", OpUnion)]
+    _fields_ = [("kind", i32), ("lane", i32), ("u", OpUnion)]
 
 
 # every symbol include/mfcnet_hip.h declares

@@ -72,6 +72,7 @@ class HRNetMultiHIP(nn.Module):
         self.width = width
         self.compute_dtype = _DT[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype
         self.fuse_bn = fuse_bn
+        self.parallel_branches = True      # run the independent branches of each HRNet module on parallel HIP streams
         self._entries: List[Entry] = hrnet_entries(width, num_classes) + head_entries(
             self.basic, num_classes, num_frames, optflow_inputs, depth_inputs)
         self._poff: Dict[str, int] = {}

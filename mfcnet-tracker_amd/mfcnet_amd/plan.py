@@ -105,6 +105,29 @@ class ConvInfo:
     wg: Optional[object] = None                   # weight-gradient launch descriptor (x / dy pointers filled at backward emission)
 
 
+class _Recs(list):
+    """Program records (kind, descriptor); append() tags the plan's current lane."""
+
+    def __init__(self, plan):
+        super().__init__()
+        self.plan = plan
+
+    def append(self, item):
+        super().append((item[0], item[1], self.plan.cur_lane))
+
+
+class _Ops(list):
+    """Forward graph nodes; remembers the lane each one was emitted on (its backward records run on the same lane)."""
+
+    def __init__(self, plan):
+        super().__init__()
+        self.plan, self.lanes = plan, []
+
+    def append(self, item):
+        super().append(item)
+        self.lanes.append(self.plan.cur_lane)
+
+
 class Plan:
     def __init__(self, model, B, H, W, has_flow, has_depth, base_training, head_training, need_backward, device):
         self.m = model
@@ -119,6 +142,7 @@ class Plan:
         self.need_backward = need_backward
         self.device = device
         self.fuse_bn = model.fuse_bn
+        self.lanes = getattr(model, "parallel_branches", True)      # branch-parallel lanes of the program (include/mfcnet_hip.h, mfc_op.lane)
         self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc")}
         self._build()                       # dry pass: sizes
         for a in self.arenas.values():
@@ -271,7 +295,8 @@ class Plan:
     def _build(self):
         for a in self.arenas.values():
             a.reset()
-        self.fwd, self.bwd, self.ops = [], [], []
+        self.cur_lane = 0
+        self.fwd, self.bwd, self.ops = _Recs(self), _Recs(self), _Ops(self)
         self.pack_jobs, self.unpack_jobs = [], []
         m, B, T, H, W, nc = self.m, self.B, self.T, self.H, self.W, self.nc
         self.grad_base = m._G.data_ptr()
@@ -357,12 +382,14 @@ class Plan:
             xs = list(xs)
             for i in range(nb):
                 v = xs[i]
+                self.cur_lane = i + 1 if (nb > 1 and self.lanes) else 0      # the branches of a module are independent (hrnet.py:242-243)
                 for b in range(4):                           # BasicBlock, hrnet.py:58-74
                     r = f"{q}branches.{i}.{b}."
                     o = self.cbr(v, r + "conv1", r + "bn1", ch[i], 3, 1, True, tr)
                     o = self.conv(o, r + "conv2.weight", ch[i], 3, 1, False, r + "bn2", tr)
                     v = self.combine([Term(o.t, o.bn), Term(v.t)], True)
                 xs[i] = v
+            self.cur_lane = 0
             outs = []
             for i in range(nb):
                 terms = []
@@ -434,8 +461,9 @@ class Plan:
 
     def _emit_backward(self):
         E, Cs = self.E, None
-        for op in reversed(self.ops):
+        for op, lane in zip(reversed(self.ops), reversed(self.ops.lanes)):
             kind = op[0]
+            self.cur_lane = lane
             if kind == "out":
                 o = op[1]
                 g = self.grad_of(o)
@@ -520,6 +548,9 @@ class Plan:
                 k, s, pad = ci.k, ci.stride, ci.pad
                 ci.wg.x, ci.wg.dy = xt.ptr, dy.ptr
                 self.bwd.append((L.OP_WGRAD, ci.wg))
+                if self.lanes:      # detached: nothing reads the partial sums before the final unpack
+                    k_, d_, ln_ = self.bwd[-1]
+                    self.bwd[-1] = (k_, d_, ln_ | L.LANE_ASYNC)
                 if ci.bias:
                     r = L.RawOp(dy.ptr, self.gptr(ci.bias), 0, y.N * y.H * y.W)
                     r.i[0:3] = [self.dtype, y.Cp, ci.cout]
@@ -534,7 +565,10 @@ class Plan:
                     if x.bn is not None:
                         xt.virtual_consumed, xt.virtual_relu = True, x.relu
 
+        self.cur_lane = 0
+
     # ------------------------------------------------------------------ program arrays
+
     def _jobs(self, jobs, cls, per_block):
         arr = (cls * len(jobs))()
         b0 = 0
@@ -553,8 +587,10 @@ class Plan:
 
     def _program(self, recs):
         arr = (L.Op * len(recs))()
-        for i, (kind, d) in enumerate(recs):
+        for i, rec in enumerate(recs):
+            kind, d = rec[0], rec[1]
             arr[i].kind = kind
+            arr[i].lane = rec[2] if len(rec) > 2 else 0
             C.memmove(C.byref(arr[i].u), C.byref(d), C.sizeof(d))
         return arr
 
