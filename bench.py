@@ -118,6 +118,10 @@ def main():
 
     if args.serial:
         L.lib.mfc_set_flag(9, 0)
+    if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
+        L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_ASYNC_STREAMS"):
+        L.lib.mfc_set_flag(10, int(os.environ["MFC_ASYNC_STREAMS"]))
     for _ in range(args.warmup):
         step()
     sync()

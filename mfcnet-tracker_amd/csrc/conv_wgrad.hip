@@ -20,9 +20,11 @@ int mfc_conv_set_force_mt(int v);
 int mfc_conv_set_grid(int v);
 int mfc_conv_set_ablate(int v);
 static int g_wgrad_ablate = 0;
+static int g_wgrad_blocks = 512;     // target workgroups per wave-kernel launch (S = blocks / Y); tuning: mfc_set_flag(11, n)
 int mfc_conv_set_lds_kb(int v);
 int mfc_conv_set_ybfast(int v);
 int mfc_set_lanes(int on);
+int mfc_set_async_streams(int n);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
@@ -33,6 +35,8 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 7) { g_wgrad_ablate = value; return 0; }
     if (id == 8) return mfc_conv_set_ybfast(value);
     if (id == 9) return mfc_set_lanes(value);
+    if (id == 10) return mfc_set_async_streams(value);
+    if (id == 11) { g_wgrad_blocks = value > 0 ? value : 512; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
 
@@ -931,7 +935,7 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) 
     if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
     const int Y = (f.TA / TAA) * f.co_blocks * f.ci_blocks;
     int S = d->splits;
-    if (S <= 0) S = ceil_div(512, Y);      // 2 workgroups per CU (the flush is a plain store of the partial sums: extra workgroups are cheap)
+    if (S <= 0) S = ceil_div(g_wgrad_blocks, Y);      // 2 workgroups per CU (the flush is a plain store of the partial sums: extra workgroups are cheap)
     if (S * 4 > f.ntiles) S = ceil_div(f.ntiles, 4);
     if (S < 1) S = 1;
     f.splits = S;

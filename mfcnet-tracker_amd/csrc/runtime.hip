@@ -278,7 +278,7 @@ static int run_one(const mfc_op& o, void* stream) {
 // must not touch each other's outputs (the plan guarantees it: nothing in the arenas is reused, and a branch only writes
 // its own tensors).  Under-filled launches of the low-resolution branches then share the GPU with the other branches.
 #define MFC_MAX_LANES 8
-#define MFC_ASYNC_STREAMS 2
+#define MFC_ASYNC_STREAMS 4
 #define MFC_ASYNC_EVENTS 16
 struct LaneSet {
     hipStream_t s[MFC_MAX_LANES + 1]; hipEvent_t fork, join[MFC_MAX_LANES + 1];
@@ -287,7 +287,9 @@ struct LaneSet {
 };
 static LaneSet g_lanes[16];
 static int g_lanes_on = 3;       // bit 0: parallel-section lanes, bit 1: detached (async) records
+static int g_async_n = 1;        // async streams in use (1..MFC_ASYNC_STREAMS; measured: 1 is best, concurrent wgrads fight each other); tuning: mfc_set_flag(10, n)
 int mfc_set_lanes(int on) { g_lanes_on = on; return 0; }
+int mfc_set_async_streams(int n) { g_async_n = n < 1 ? 1 : (n > MFC_ASYNC_STREAMS ? MFC_ASYNC_STREAMS : n); return 0; }
 
 static LaneSet* lanes_for_device() {
     int dev = 0;
@@ -354,7 +356,7 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
             (void)hipEventRecord(ev, (hipStream_t)st);
             (void)hipStreamWaitEvent(L->as[anext], ev, 0);
             st = (void*)L->as[anext];
-            aused |= 1u << anext; anext = (anext + 1) % MFC_ASYNC_STREAMS;
+            aused |= 1u << anext; anext = (anext + 1) % g_async_n;
         }
         const int rc = run_one(ops[i], st);
         if (rc != MFC_OK) { if (in_par) join(); if (aused) join_async(); return -(1000 * (i + 1)) + rc; }

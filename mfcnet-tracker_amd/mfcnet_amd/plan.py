@@ -395,6 +395,9 @@ class Plan:
                 terms = []
                 for j in range(nb):
                     r = f"{q}fuse_layers.{i}.{j}."
+                    # path (i, j) reads branch j and is the only writer of grad(branch j) inside this output's section: one
+                    # lane per source branch, forward and backward (the sum itself is a serial record between the sections)
+                    self.cur_lane = j + 1 if (self.lanes and j != i) else 0
                     if j == i:
                         terms.append(Term(xs[j].t))
                     elif j > i:                              # 1x1 + BN, then bilinear up-sampling
@@ -410,6 +413,7 @@ class Plan:
                             else:
                                 v = self.cbr(v, f"{r}{k}.0", f"{r}{k}.1", co, 3, 2, True, tr)
                         terms.append(Term(v.t, v.bn))
+                self.cur_lane = 0
                 # reference sums in j order starting from j = 0
                 outs.append(self.combine(terms, True, size=(xs[i].t.H, xs[i].t.W), C=ch[i]))
             return outs
