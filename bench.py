@@ -36,6 +36,22 @@ def synth(B, T, H, W, nc, seed, device):
     return frames, mask
 
 
+def pmc_traffic(NT, MT, PM, args):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_round.sh: two separate
+    rocprofv3 --pmc runs of this command, FETCH_SIZE doubled per MI355X_MICROARCH.md; condensed by
+    tools/summarize_profile.py).  bench.py cannot collect counters itself; null when no profile matches the configuration."""
+    tag = f"r01_d_w{args.width}_pmc_traffic.json"
+    path = os.path.join(ROOT, "profiles", tag)
+    if args.dtype != "bf16" or (args.batch, args.frames, args.height, args.width_px) != (8, 3, 480, 640) or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        ks = json.load(f)["kernels"]
+    for name, v in ks.items():
+        if "conv_igemm_kernel" in name and f"Li{NT}ELi{MT}ELi{PM}E" in name and "DF16b" in name:
+            return v["hbm_bytes_per_launch"], f"profiles/{tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial`)"
+    return None, None
+
+
 def cpu_baseline(width, T, H, W, steps=2):
     """The CPU oracle's training step on the host cores (bounded sample)."""
     from oracle import mfcnet_oracle as O
@@ -59,7 +75,7 @@ def cpu_baseline(width, T, H, W, steps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=32, help="HRNet width: 32 = BASELINE.json metric label, 48 = reference")
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
@@ -150,31 +166,36 @@ def main():
     final_loss = float(loss)
 
     if rank == 0:
-        # dominant kernel = the conv_igemm instantiation with the largest total time
-        base = 8 if args.dtype == "bf16" else 0
-        best, roof = None, None
-        tot_conv_ms = sum(prof.ms[i] for i in range(32))
-        for slot, nt in enumerate(NT_SLOTS):
-            b = base + slot
-            if prof.launches[b] and (best is None or prof.ms[b] > prof.ms[best]):
-                best = b
-        if best is not None:
+        # dominant kernel = the conv_igemm instantiation (one profiler bucket per <NT, MT, PMAX>, as rocprof names them) with the
+        # largest total time in the profiled step; bucket layout: include/mfcnet_hip.h (mfc_prof_result)
+        dt_base = 32 if args.dtype == "bf16" else 0
+        roof = None
+        conv = [(dt_base + s, s) for s in range(20)]
+        live = [(b, s) for b, s in conv if prof.launches[b]]
+        if live:
+            best, bslot = max(live, key=lambda bs: prof.ms[bs[0]])
             n = prof.launches[best]
             avg_ms = prof.ms[best] / n
             achieved = prof.flops[best] / n / (avg_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
-            fam_ms = sum(prof.ms[base + s] for s in range(5))
-            fam_fl = sum(prof.flops[base + s] for s in range(5))
-            wg_ms = sum(prof.ms[16 + base + s] for s in range(3))
-            wg_fl = sum(prof.flops[16 + base + s] for s in range(3))
-            roof = {"bound": "mfma", "kernel": f"conv_igemm_kernel<{'bf16' if args.dtype == 'bf16' else 'float'}, {NT_SLOTS[best - base]}>",
+            NT = NT_SLOTS[bslot // 4]
+            MT, PM = [(4, 3), (4, 6), (2, 4), (2, 10)][bslot % 4]
+            kname = f"conv_igemm_kernel<{'__bf16' if args.dtype == 'bf16' else 'float'}, {NT}, {MT}, {PM}>"
+            fam_ms = sum(prof.ms[b] for b, _ in conv)
+            fam_fl = sum(prof.flops[b] for b, _ in conv)
+            wgb = [64 + dt_base + s for s in range(32)]
+            wg_ms = sum(prof.ms[b] for b in wgb)
+            wg_fl = sum(prof.flops[b] for b in wgb)
+            traffic, tsrc = pmc_traffic(NT, MT, PM, args)
+            roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": n // max(prof_steps, 1),
+                    "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(prof.bytes[best] / n),
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": n // max(prof_steps, 1),
                     "flops_per_launch": prof.flops[best] / n,
                     "all_conv_igemm_tflops": round(fam_fl / (fam_ms * 1e-3) / 1e12, 2) if fam_ms else None,
                     "all_wgrad_tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms else None,
                     "conv_ms_per_step": round(fam_ms / max(prof_steps, 1), 3), "wgrad_ms_per_step": round(wg_ms / max(prof_steps, 1), 3),
-                    "profiled_steps": prof_steps}
+                    "profiled_steps": prof_steps, "profiled_step_streams": "serial"}
         out = {"metric": "frames/sec (480x640, T=3, HRNet MFCNet) fwd+bwd", "value": round(world * B * T * args.steps / dt, 2),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",

@@ -356,9 +356,11 @@ int mfc_program_profile(const mfc_op* ops, int32_t n, int32_t reps, float* ms_ou
 /* In-process kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
  * While enabled, every conv forward/dgrad and wgrad launch is bracketed by two events; mfc_prof_collect
  * synchronises and sums elapsed time, launches and algorithmic FLOPs per bucket.
- * bucket = family*16 + dtype*8 + slot;  family 0 = conv_igemm (slot: NT index {1,2,3,4,6} -> 0..4),
- * family 1 = conv_wgrad (slot: TPW index {8,16,28} -> 0..2).                                          */
-#define MFC_PROF_BUCKETS 32
+ * bucket = family*64 + dtype*32 + slot (dtype 0 = fp32, 1 = bf16);
+ *   family 0 = conv_igemm_kernel<T, NT, MT, PMAX>: slot = ntIndex*4 + variant, NT in {1,2,3,4,6} -> ntIndex 0..4,
+ *              variant 0..3 = <MT,PMAX> in {<4,3>, <4,6>, <2,4>, <2,10>}   (one bucket per kernel instantiation, as rocprof sees it)
+ *   family 1 = weight gradient: slot 0..2 generic kernel (TPW 8/16/28), 8..10 fast kernel (TB 1/3/11), 16..17 wave kernel (TB 3/11) */
+#define MFC_PROF_BUCKETS 128
 typedef struct { double ms[MFC_PROF_BUCKETS]; double flops[MFC_PROF_BUCKETS]; double bytes[MFC_PROF_BUCKETS]; int64_t launches[MFC_PROF_BUCKETS]; } mfc_prof_result;
 int mfc_prof_enable(int on);
 int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded events, fills `out`, clears the log */

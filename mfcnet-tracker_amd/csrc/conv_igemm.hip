@@ -516,11 +516,12 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
         attr_set = true;
     }
     if (g_mfc_prof_on) {
-        const int slot = NT == 1 ? 0 : NT == 2 ? 1 : NT == 3 ? 2 : NT == 4 ? 3 : 4;
+        const int nti = NT == 1 ? 0 : NT == 2 ? 1 : NT == 3 ? 2 : NT == 4 ? 3 : 4;
+        const int slot = nti * 4 + (MT == 4 ? (PMAX == 3 ? 0 : 1) : (PMAX == 4 ? 2 : 3));
         const double E = sizeof(T) == 2 ? 8.0 : 4.0;
         const double flops = 2.0 * k.N * k.Hl * k.Wl * (double)k.Cout * k.TA * k.TB * (k.Cin_g * E);
         const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_g * 16.0) / (k.osh * k.osw) + (double)k.N * k.Hl * k.Wl * k.Cout_p * sizeof(T);
-        mfc_prof_before(st, 0 * 16 + (sizeof(T) == 2 ? 8 : 0) + slot, flops, bytes);
+        mfc_prof_before(st, 0 * 64 + (sizeof(T) == 2 ? 32 : 0) + slot, flops, bytes);
     }
     hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT, PMAX>), dim3(grid), dim3(256), lds, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);

@@ -108,7 +108,7 @@ class LossDesc(C.Structure):
 
 
 class ProfResult(C.Structure):
-    _fields_ = [("ms", C.c_double * 32), ("flops", C.c_double * 32), ("bytes", C.c_double * 32), ("launches", C.c_int64 * 32)]
+    _fields_ = [("ms", C.c_double * 128), ("flops", C.c_double * 128), ("bytes", C.c_double * 128), ("launches", C.c_int64 * 128)]
 
 
 class RawOp(C.Structure):

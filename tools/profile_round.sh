@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profile of bench.py on the GPU box (run through gpurun from the repo root):
+#   1. rocprofv3 --kernel-trace --stats of the serial (one-stream) bench and of the default (lanes) bench
+#   2. two separate PMC passes (FETCH_SIZE, WRITE_SIZE) of the serial bench  -- never combined with other trace domains
+# Outputs land in gpurun_out/prof_round/ ; tools/summarize_profile.py condenses them into profiles/.
+set -e
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/prof_round
+rm -rf $OUT; mkdir -p $OUT
+W=${1:-32}
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/serial -o serial -- python3 /root/repo/bench.py --serial --width $W --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_serial.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/lanes -o lanes -- python3 /root/repo/bench.py --width $W --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_lanes.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- python3 /root/repo/bench.py --serial --width $W --steps 1 --warmup 1 --no-cpu-baseline --no-prof > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- python3 /root/repo/bench.py --serial --width $W --steps 1 --warmup 1 --no-cpu-baseline --no-prof > $OUT/bench_pmc_write.log 2>&1
+find $OUT -name "*.csv" | head -20
