@@ -136,6 +136,14 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_ASYNC_ON_LANE"):
+        L.lib.mfc_set_flag(13, int(os.environ["MFC_ASYNC_ON_LANE"]))
+    if os.environ.get("MFC_OWN_MAIN"):
+        L.lib.mfc_set_flag(14, int(os.environ["MFC_OWN_MAIN"]))
+    if os.environ.get("MFC_LANE_STREAMS"):
+        L.lib.mfc_set_flag(12, int(os.environ["MFC_LANE_STREAMS"]))
+    if os.environ.get("MFC_LANES"):
+        L.lib.mfc_set_flag(9, int(os.environ["MFC_LANES"]))
     if os.environ.get("MFC_ASYNC_STREAMS"):
         L.lib.mfc_set_flag(10, int(os.environ["MFC_ASYNC_STREAMS"]))
     for _ in range(args.warmup):

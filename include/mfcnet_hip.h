@@ -350,6 +350,13 @@ typedef struct {
 } mfc_op;
 /* runs ops[0..n); returns 0 or (-(1000*index) + status) of the first failing record */
 int mfc_program_run(const mfc_op* ops, int32_t n, void* stream);
+/* hipGraph form of a program: capture once (the program must have run once before; `stream` must not be the null
+ * stream; section lanes / detached records become parallel graph branches), replay with mfc_graph_launch.  All pointers in
+ * the records are baked into the graph, which is what the static plan guarantees.  Measured on MI355X / ROCm 7.2: no faster
+ * than mfc_program_run (the step is GPU-bound and the host already runs ahead), so the Python layer does not use it. */
+int mfc_graph_capture(const mfc_op* ops, int32_t n, void* stream, void** exec_out);
+int mfc_graph_launch(void* exec, void* stream);
+int mfc_graph_destroy(void* exec);
 /* tuning aid: the same, with a HIP event between records (each record launched `reps` times back to back);
  * synchronises the stream and returns the stream time per record and repetition in ms_out[n] */
 int mfc_program_profile(const mfc_op* ops, int32_t n, int32_t reps, float* ms_out, void* stream);

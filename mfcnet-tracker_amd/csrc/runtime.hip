@@ -280,15 +280,35 @@ static int run_one(const mfc_op& o, void* stream) {
 #define MFC_MAX_LANES 8
 #define MFC_ASYNC_STREAMS 4
 #define MFC_ASYNC_EVENTS 16
+// Streams of one device.  m = the interpreter's own main stream, s[2..] the side lanes, as[] the detached streams: created
+// back to back so HIP's round-robin stream -> hardware-queue mapping (4 queues by default) gives the four streams in use
+// (m, s[2], s[3], as[0]) distinct queues whatever stream the caller runs on.  (Measured: on a caller stream that happened to
+// share a queue with a lane the lanes gained nothing; with >8 hardware queues the firmware time-slices and everything is slower.)
 struct LaneSet {
-    hipStream_t s[MFC_MAX_LANES + 1]; hipEvent_t fork, join[MFC_MAX_LANES + 1];
+    hipStream_t m, s[MFC_MAX_LANES + 1]; hipEvent_t enter, leave, fork, join[MFC_MAX_LANES + 1];
     hipStream_t as[MFC_ASYNC_STREAMS]; hipEvent_t aev[MFC_ASYNC_EVENTS], ajoin[MFC_ASYNC_STREAMS];
     bool ready;
 };
 static LaneSet g_lanes[16];
 static int g_lanes_on = 3;       // bit 0: parallel-section lanes, bit 1: detached (async) records
+static int g_lane_streams = 3;   // streams the section lanes are folded onto (1 = main only; measured best: 3 + the detached stream, more co-running persistent kernels thrash); tuning: mfc_set_flag(12, n)
+static int g_lane_map[MFC_MAX_LANES + 1] = {0, 1, 2, 2, 1, 0, 0, 0, 0};   // lane -> stream (0 = fold by modulo).  Measured best for the 4 HRNet branches: the
+                                                                          // 120x160 and 15x20 branches on the main stream, the two middle ones on one side stream
+int mfc_set_lane_streams(int n) {
+    if (n >= 1000) {          // decimal digits = streams of lanes 1..4, e.g. 1223
+        g_lane_map[1] = n / 1000 % 10; g_lane_map[2] = n / 100 % 10; g_lane_map[3] = n / 10 % 10; g_lane_map[4] = n % 10;
+        return 0;
+    }
+    for (int i = 0; i <= MFC_MAX_LANES; ++i) g_lane_map[i] = 0;
+    g_lane_streams = n < 1 ? 1 : (n > MFC_MAX_LANES ? MFC_MAX_LANES : n); return 0;
+}
 static int g_async_n = 1;        // async streams in use (1..MFC_ASYNC_STREAMS; measured: 1 is best, concurrent wgrads fight each other); tuning: mfc_set_flag(10, n)
 int mfc_set_lanes(int on) { g_lanes_on = on; return 0; }
+static int g_async_on_lane = 0;  // 0: detached records on their own stream; k >= 2: on side lane k's stream; tuning: mfc_set_flag(13, k)
+static int g_own_main = 0;       // 1: the program's main stream is the interpreter's own (immune to a caller stream that shares a hardware queue with a
+                                 // side stream, 1.5 % slower); 0: the caller's; tuning: mfc_set_flag(14, v)
+int mfc_set_async_on_lane(int k) { g_async_on_lane = k; return 0; }
+int mfc_set_own_main(int v) { g_own_main = v; return 0; }
 int mfc_set_async_streams(int n) { g_async_n = n < 1 ? 1 : (n > MFC_ASYNC_STREAMS ? MFC_ASYNC_STREAMS : n); return 0; }
 
 static LaneSet* lanes_for_device() {
@@ -296,15 +316,21 @@ static LaneSet* lanes_for_device() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     LaneSet* L = &g_lanes[dev];
     if (!L->ready) {
-        for (int i = 2; i <= MFC_MAX_LANES; ++i)
+        if (hipStreamCreateWithFlags(&L->m, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 2; i <= 3; ++i)
             if (hipStreamCreateWithFlags(&L->s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&L->as[0], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 4; i <= MFC_MAX_LANES; ++i)
+            if (hipStreamCreateWithFlags(&L->s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 1; i < MFC_ASYNC_STREAMS; ++i)
+            if (hipStreamCreateWithFlags(&L->as[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&L->enter, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&L->leave, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&L->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
         for (int i = 2; i <= MFC_MAX_LANES; ++i)
             if (hipEventCreateWithFlags(&L->join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        for (int i = 0; i < MFC_ASYNC_STREAMS; ++i) {
-            if (hipStreamCreateWithFlags(&L->as[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 0; i < MFC_ASYNC_STREAMS; ++i)
             if (hipEventCreateWithFlags(&L->ajoin[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        }
         for (int i = 0; i < MFC_ASYNC_EVENTS; ++i)
             if (hipEventCreateWithFlags(&L->aev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         L->ready = true;
@@ -312,14 +338,23 @@ static LaneSet* lanes_for_device() {
     return L;
 }
 
+static bool g_capturing = false;      // (a captured program stays on the capturing stream: see mfc_graph_capture)
+
 // Detached records (lane bit MFC_LANE_ASYNC): work whose result nothing in the program reads before the next
 // MFC_OP_UNPACK / the program end -- the weight gradients.  Such a record waits (event) for everything issued so far on
-// the stream it would have run on, then runs on one of two extra streams, so the MFMA-bound wgrad launches overlap the
-// HBM-bound BatchNorm-backward sweeps and the data-gradient chain instead of sitting in it.
+// the stream it would have run on, then runs on an extra stream, so the MFMA-bound wgrad launches overlap the HBM-bound
+// BatchNorm-backward sweeps and the data-gradient chain instead of sitting in it.
 extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
     if (!ops || n < 0) return MFC_ERR_INVALID_ARG;
-    hipStream_t mainst = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
     LaneSet* L = nullptr;
+    bool multi = false;
+    if (g_lanes_on)
+        for (int i = 0; i < n && !multi; ++i) multi = ops[i].lane != 0;
+    if (multi && !(L = lanes_for_device())) return MFC_ERR_LAUNCH;
+    // with lanes the whole program runs on the interpreter's own streams, ordered after / before the caller's stream by events
+    hipStream_t mainst = (multi && !g_capturing && g_own_main) ? L->m : caller;
+    if (mainst != caller) { (void)hipEventRecord(L->enter, caller); (void)hipStreamWaitEvent(mainst, L->enter, 0); }
     bool in_par = false; unsigned used = 0;
     unsigned aused = 0; int anext = 0, aevn = 0;
     auto join = [&]() {
@@ -329,41 +364,76 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
     };
     auto join_async = [&]() {
         for (int a = 0; a < MFC_ASYNC_STREAMS; ++a)
-            if (aused & (1u << a)) { (void)hipEventRecord(L->ajoin[a], L->as[a]); (void)hipStreamWaitEvent(mainst, L->ajoin[a], 0); }
+            if (aused & (1u << a)) {
+                hipStream_t src = (g_async_on_lane >= 2 && g_async_on_lane <= MFC_MAX_LANES) ? L->s[g_async_on_lane] : L->as[a];
+                (void)hipEventRecord(L->ajoin[a], src); (void)hipStreamWaitEvent(mainst, L->ajoin[a], 0);
+            }
         aused = 0;
     };
+    auto leave = [&]() {
+        if (mainst != caller) { (void)hipEventRecord(L->leave, mainst); (void)hipStreamWaitEvent(caller, L->leave, 0); }
+    };
     for (int i = 0; i < n; ++i) {
-        const int lane = (g_lanes_on & 1) ? (ops[i].lane & 0xff) : 0;
-        const bool detached = (g_lanes_on & 2) && (ops[i].lane & MFC_LANE_ASYNC);
-        void* st = stream;
+        int lane = (multi && (g_lanes_on & 1)) ? (ops[i].lane & 0xff) : 0;
+        if (lane >= 1 && lane <= MFC_MAX_LANES && g_lane_map[lane]) lane = g_lane_map[lane];
+        else if (lane > g_lane_streams) lane = (lane - 1) % g_lane_streams + 1;      // fold the lanes onto the streams in use
+        const bool detached = multi && (g_lanes_on & 2) && (ops[i].lane & MFC_LANE_ASYNC);
+        hipStream_t st = mainst;
         if (lane >= 2 && lane <= MFC_MAX_LANES) {
-            if (!L && !(L = lanes_for_device())) return -(1000 * (i + 1)) + MFC_ERR_LAUNCH;
             if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; }
             if (!(used & (1u << lane))) { (void)hipStreamWaitEvent(L->s[lane], L->fork, 0); used |= 1u << lane; }
-            st = (void*)L->s[lane];
+            st = L->s[lane];
         } else if (lane == 1) {
-            if (!in_par) {
-                if (!L && !(L = lanes_for_device())) return -(1000 * (i + 1)) + MFC_ERR_LAUNCH;
-                (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0;
-            }
+            if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; }
         } else if (in_par) {
             join();
         }
         if (ops[i].kind == MFC_OP_UNPACK && aused) join_async();       // (lane 0: the side lanes were joined just above)
         if (detached) {
-            if (!L && !(L = lanes_for_device())) return -(1000 * (i + 1)) + MFC_ERR_LAUNCH;
             hipEvent_t ev = L->aev[aevn]; aevn = (aevn + 1) % MFC_ASYNC_EVENTS;
-            (void)hipEventRecord(ev, (hipStream_t)st);
-            (void)hipStreamWaitEvent(L->as[anext], ev, 0);
-            st = (void*)L->as[anext];
+            (void)hipEventRecord(ev, st);
+            hipStream_t dst = (g_async_on_lane >= 2 && g_async_on_lane <= MFC_MAX_LANES) ? L->s[g_async_on_lane] : L->as[anext];
+            if (dst != st) (void)hipStreamWaitEvent(dst, ev, 0);
+            st = dst;
             aused |= 1u << anext; anext = (anext + 1) % g_async_n;
         }
-        const int rc = run_one(ops[i], st);
-        if (rc != MFC_OK) { if (in_par) join(); if (aused) join_async(); return -(1000 * (i + 1)) + rc; }
+        const int rc = run_one(ops[i], (void*)st);
+        if (rc != MFC_OK) { if (in_par) join(); if (aused) join_async(); leave(); return -(1000 * (i + 1)) + rc; }
     }
     if (in_par) join();
     if (aused) join_async();
+    leave();
     return MFC_OK;
+}
+
+// hipGraph capture of a whole program (lanes become parallel graph branches).  `stream` must not be the null stream.
+// The caller must have run the program once normally (first launches set function attributes, which is not a stream operation).
+extern "C" int mfc_graph_capture(const mfc_op* ops, int32_t n, void* stream, void** exec_out) {
+    if (!ops || n <= 0 || !stream || !exec_out) return MFC_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_mfc_prof_on) return MFC_ERR_UNSUPPORTED;
+    if (!lanes_for_device()) return MFC_ERR_LAUNCH;                  // create side streams / events outside the capture
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) return MFC_ERR_LAUNCH;
+    g_capturing = true;
+    const int rc = mfc_program_run(ops, n, stream);
+    g_capturing = false;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != MFC_OK || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return rc != MFC_OK ? rc : MFC_ERR_LAUNCH; }
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e2 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e2 != hipSuccess || !ex) return MFC_ERR_LAUNCH;
+    *exec_out = (void*)ex;
+    return MFC_OK;
+}
+extern "C" int mfc_graph_launch(void* exec, void* stream) {
+    if (!exec) return MFC_ERR_INVALID_ARG;
+    return hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream) == hipSuccess ? MFC_OK : MFC_ERR_LAUNCH;
+}
+extern "C" int mfc_graph_destroy(void* exec) {
+    if (!exec) return MFC_ERR_INVALID_ARG;
+    return hipGraphExecDestroy((hipGraphExec_t)exec) == hipSuccess ? MFC_OK : MFC_ERR_LAUNCH;
 }
 
 // Tuning aid: run the program with a HIP event between consecutive records (each record `reps` times back to back) and

@@ -247,3 +247,55 @@ def test_engine_steps_match_golden(mfc):
     assert abs(md["metric_dice"] - ref_md["metric_dice"]) < 1e-12
     tot, parts = O.total_loss(out.cpu(), mask, 5)
     assert abs(float(acc.cpu()[28]) - float(tot)) < 1e-4
+
+
+def test_lanes_do_not_change_results(mfc):
+    """The branch lanes / the detached weight-gradient stream (mfc_op.lane) only reorder independent work: a training step
+    run with every record on one stream gives the same logits and the same gradients (weight gradients are partial-sum
+    slices added in a fixed order; only the BatchNorm statistic atomics may differ in the last bits)."""
+    from mfcnet_amd import _lib as L
+    cfg, z = load_case("large_rgb_train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    res = []
+    for flag in (0, 3):
+        L.lib.mfc_set_flag(9, flag)
+        try:
+            m = build(mfc, cfg)
+            set_mode(m, "train")
+            y = m(dev(frames))
+            loss, _ = mfc.mfc_loss(y, mask.cuda())
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((y.detach().cpu(), m._G.detach().cpu().clone()))
+        finally:
+            L.lib.mfc_set_flag(9, 3)
+    (y0, g0), (y1, g1) = res
+    assert float((y0 - y1).abs().max()) <= ATOL
+    assert rel_l2(g1.numpy(), g0.numpy()) < GRAD_RTOL      # (the order of the BN statistic atomics is the only freedom; see the noise floor above)
+
+
+def test_captured_graph_replays_the_forward_program(mfc):
+    """mfc_graph_capture / mfc_graph_launch: the forward program as a hipGraph (lanes become graph branches) writes the
+    same logits as mfc_program_run."""
+    import ctypes as C
+    from mfcnet_amd import _lib as L
+    cfg, z = load_case("large_rgb_eval")
+    m = build(mfc, cfg)
+    m.eval()
+    frames, flows, depths, mask = case_inputs(cfg)
+    with torch.no_grad():
+        y_ref = m(dev(frames)).clone()
+    plan = next(iter(m._plans.values()))
+    s = torch.cuda.Stream()
+    sp = C.c_void_p(s.cuda_stream)
+    ex = C.c_void_p()
+    torch.cuda.synchronize()
+    assert L.lib.mfc_graph_capture(plan.fwd_prog, len(plan.fwd_prog), sp, C.byref(ex)) == 0
+    out = plan._io(plan.out_buf, (plan.B, plan.nc, plan.H, plan.W))
+    out.zero_()
+    torch.cuda.synchronize()
+    assert L.lib.mfc_graph_launch(ex, sp) == 0
+    s.synchronize()
+    assert float((out - y_ref).abs().max()) <= 1e-5
+    compare_logits(z, out.cpu().numpy(), ATOL)
+    assert L.lib.mfc_graph_destroy(ex) == 0
