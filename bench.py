@@ -136,6 +136,8 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_SKIP_KINDS"):            # what-if timing only (results are wrong)
+        L.lib.mfc_set_flag(15, int(os.environ["MFC_SKIP_KINDS"]))
     if os.environ.get("MFC_ASYNC_ON_LANE"):
         L.lib.mfc_set_flag(13, int(os.environ["MFC_ASYNC_ON_LANE"]))
     if os.environ.get("MFC_OWN_MAIN"):
@@ -171,7 +173,7 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         # dominant kernel = the conv_igemm instantiation (one profiler bucket per <NT, MT, PMAX>, as rocprof names them) with the

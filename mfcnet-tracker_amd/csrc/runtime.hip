@@ -304,6 +304,8 @@ int mfc_set_lane_streams(int n) {
 }
 static int g_async_n = 1;        // async streams in use (1..MFC_ASYNC_STREAMS; measured: 1 is best, concurrent wgrads fight each other); tuning: mfc_set_flag(10, n)
 int mfc_set_lanes(int on) { g_lanes_on = on; return 0; }
+static int g_skip_kinds = 0;     // tuning only: bit k set -> records of kind k are skipped (what-if timing); mfc_set_flag(15, mask)
+int mfc_set_skip_kinds(int m) { g_skip_kinds = m; return 0; }
 static int g_async_on_lane = 0;  // 0: detached records on their own stream; k >= 2: on side lane k's stream; tuning: mfc_set_flag(13, k)
 static int g_own_main = 0;       // 1: the program's main stream is the interpreter's own (immune to a caller stream that shares a hardware queue with a
                                  // side stream, 1.5 % slower); 0: the caller's; tuning: mfc_set_flag(14, v)
@@ -397,7 +399,7 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
             st = dst;
             aused |= 1u << anext; anext = (anext + 1) % g_async_n;
         }
-        const int rc = run_one(ops[i], (void*)st);
+        const int rc = (g_skip_kinds >> ops[i].kind) & 1 ? MFC_OK : run_one(ops[i], (void*)st);
         if (rc != MFC_OK) { if (in_par) join(); if (aused) join_async(); leave(); return -(1000 * (i + 1)) + rc; }
     }
     if (in_par) join();
