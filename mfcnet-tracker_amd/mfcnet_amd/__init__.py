@@ -4,7 +4,8 @@ Drop-in for the reference's `models.get_multiframe_segmentation_model` on the
 `HRNetMulti-Large` / `HRNetMulti-Basic` model types (models/__init__.py:79-84).
 """
 from ._lib import BF16, F32, MfcError, lib  # noqa: F401  (importing loads libmfcnet_hip.so or raises)
-from .model import HRNetMultiBasic, HRNetMultiLarge, get_multiframe_segmentation_model  # noqa: F401
+from .model import (HighResolutionNetHIP, HRNetMultiBasic, HRNetMultiLarge, get_multiframe_segmentation_model,  # noqa: F401
+                    get_tooltip_segmentation_model)
 from .optim import FlatAdam  # noqa: F401
 from .loss import mfc_loss  # noqa: F401
 from .metrics import confusion_counts, get_metrics  # noqa: F401

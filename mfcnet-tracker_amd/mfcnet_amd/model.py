@@ -62,6 +62,7 @@ class HRNetMultiHIP(nn.Module):
     """HRNetMultiLarge / HRNetMultiBasic on MI355X (constructor mirrors multiframe_model.py:409,442)."""
 
     basic = False
+    single = False          # True: single-frame HighResolutionNet (no temporal head), see HighResolutionNetHIP
 
     def __init__(self, num_classes=2, num_frames=1, pretrained=True, loadpath=None, optflow_inputs=False,
                  depth_inputs=False, width=48, compute_dtype="fp32", fuse_bn=True):
@@ -73,8 +74,11 @@ class HRNetMultiHIP(nn.Module):
         self.compute_dtype = _DT[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype
         self.fuse_bn = fuse_bn
         self.parallel_branches = True      # run the independent branches of each HRNet module on parallel HIP streams
-        self._entries: List[Entry] = hrnet_entries(width, num_classes) + head_entries(
-            self.basic, num_classes, num_frames, optflow_inputs, depth_inputs)
+        if self.single:
+            self._entries: List[Entry] = hrnet_entries(width, num_classes, p="")
+        else:
+            self._entries = hrnet_entries(width, num_classes) + head_entries(
+                self.basic, num_classes, num_frames, optflow_inputs, depth_inputs)
         self._poff: Dict[str, int] = {}
         self._boff: Dict[str, int] = {}
         self._noff: Dict[str, int] = {}
@@ -89,7 +93,7 @@ class HRNetMultiHIP(nn.Module):
             elif e.kind == "bn_nbt":
                 self._noff[e.name] = nn_
                 nn_ += 1
-        self._n_base = min(off for n, off in self._poff.items() if n.startswith("multiframe_net."))
+        self._n_base = np_ if self.single else min(off for n, off in self._poff.items() if n.startswith("multiframe_net."))
         self._np, self._nb, self._nn = np_, nb, nn_
         self.add_module("base_model", _Node())
         self.add_module("multiframe_net", _Node())
@@ -167,14 +171,15 @@ class HRNetMultiHIP(nn.Module):
     # ------------------------------------------------------------------ execution
     def _get_plan(self, B, H, W, has_flow, has_depth, need_bwd, device):
         from .plan import Plan
-        key = (B, H, W, has_flow, has_depth, self.base_model.training, self.multiframe_net.training, need_bwd,
+        base_tr = self.training if self.single else self.base_model.training
+        key = (B, H, W, has_flow, has_depth, base_tr, self.multiframe_net.training, need_bwd,
                self.compute_dtype, self.fuse_bn)
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) >= 2:
                 self._plans.clear()
                 torch.cuda.empty_cache()
-            plan = Plan(self, B, H, W, has_flow, has_depth, self.base_model.training, self.multiframe_net.training,
+            plan = Plan(self, B, H, W, has_flow, has_depth, base_tr, self.multiframe_net.training,
                         need_bwd, device)
             self._plans[key] = plan
         return plan
@@ -214,11 +219,31 @@ class HRNetMultiHIP(nn.Module):
 
     # segments of the flat arenas = the reference's two optimizer groups
     def flat_segments(self):
+        if self.single:
+            return {"base_model": (0, self._np)}
         return {"base_model": (0, self._n_base), "multiframe_net": (self._n_base, self._np)}
 
 
 class HRNetMultiLarge(HRNetMultiHIP):
     basic = False
+
+
+class HighResolutionNetHIP(HRNetMultiHIP):
+    """Single-frame `HighResolutionNet` (models/hrnet.py:271-476) with the `last_layer` of the reference's 'HRNet' model type
+    (models/__init__.py:38-46: 1x1 conv + BN + ReLU + 1x1 conv to `num_classes`): `forward(x)` takes ONE `[B,3,H,W]` tensor and
+    returns `[B,num_classes,H,W]` logits (the x4 up-sampled map, hrnet.py:473-474).  Its `state_dict()` has the HRNet keys
+    without prefix, i.e. exactly what `model.base_model.load_state_dict(ckpt['model'])` of the multi-frame models consumes
+    (scripts/train_multiframe_detection.py:115-118).  Same kernels, same plan, T = 1, no temporal head."""
+    single = True
+
+    def __init__(self, num_classes=5, width=48, compute_dtype="fp32", fuse_bn=True):
+        super().__init__(num_classes=num_classes, num_frames=1, pretrained=False, loadpath=None, optflow_inputs=False,
+                         depth_inputs=False, width=width, compute_dtype=compute_dtype, fuse_bn=fuse_bn)
+
+    def forward(self, x):
+        if isinstance(x, (list, tuple)):
+            raise ValueError("the single-frame HRNet takes one [B,3,H,W] tensor")
+        return super().forward([x])
 
 
 class HRNetMultiBasic(HRNetMultiHIP):
@@ -230,6 +255,18 @@ def _warp_grid():
     H, W = 576, 720
     y, x = torch.meshgrid(torch.arange(0, H), torch.arange(0, W), indexing="ij")
     return torch.stack((2.0 * x / (W - 1) - 1.0, 2.0 * y / (H - 1) - 1.0), dim=0).float().unsqueeze(0)
+
+
+def get_tooltip_segmentation_model(args, **kw):
+    """models/__init__.py:24-52 for the 'HRNet' model type (the single-frame base the multi-frame models are seeded from).
+    The reference also loads `models/hrnet_cs_8090_torch11.pth` before swapping `last_layer`; no pretrained file exists here,
+    so weights start from the default initialisers (load a checkpoint with `load_model_weights`)."""
+    for k in ("width", "compute_dtype", "fuse_bn"):
+        if k not in kw and hasattr(args, k):
+            kw[k] = getattr(args, k)
+    if args.model_type == "HRNet":
+        return HighResolutionNetHIP(num_classes=args.num_classes, **kw)
+    raise ValueError(f"Model type {args.model_type} not recognized")
 
 
 def get_multiframe_segmentation_model(args, **kw):

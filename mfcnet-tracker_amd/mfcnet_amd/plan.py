@@ -134,6 +134,8 @@ class Plan:
         self.B, self.H, self.W = B, H, W
         self.T, self.nc, self.width = model.num_frames, model.num_classes, model.width
         self.basic = model.basic
+        self.single = getattr(model, "single", False)              # single-frame HighResolutionNet: no temporal head
+        self.base_prefix = "" if self.single else "base_model."
         self.has_flow, self.has_depth = has_flow, has_depth
         self.dtype = model.compute_dtype
         self.esz = 2 if self.dtype == L.BF16 else 4
@@ -328,13 +330,17 @@ class Plan:
         hd.H, hd.W, hd.Cp, hd.warp = H, W, xh.Cp, 1 if basic_warp else 0
         self.fwd.append((L.OP_HEAD_FWD, hd))
         self.ops.append(("head", logits, xh, hd))
-        # ---- temporal aggregation head (multiframe_model.py:191-202)
-        q = "multiframe_net.multiframe_net."
-        ht = self.head_training
-        a = self.cbr(Act(xh), q + "0", q + "1", T * nc, 11, 1, True, ht)
-        a = self.cbr(a, q + "3", q + "4", T * nc, 3, 1, True, ht)
-        a = self.cbr(a, q + "6", q + "7", T * nc, 3, 1, True, ht)
-        o = self.conv(a, q + "9.weight", nc, 1).t
+        if self.single:
+            # single-frame HighResolutionNet (hrnet.py:473-474): the x4 up-sampled logits ARE the output
+            o = xh
+        else:
+            # ---- temporal aggregation head (multiframe_model.py:191-202)
+            q = "multiframe_net.multiframe_net."
+            ht = self.head_training
+            a = self.cbr(Act(xh), q + "0", q + "1", T * nc, 11, 1, True, ht)
+            a = self.cbr(a, q + "3", q + "4", T * nc, 3, 1, True, ht)
+            a = self.cbr(a, q + "6", q + "7", T * nc, 3, 1, True, ht)
+            o = self.conv(a, q + "9.weight", nc, 1).t
         r = L.RawOp(o.ptr, self.out_buf, 0, 0)
         r.i[0:6] = [self.dtype, B, nc, H, W, o.Cp]
         self.fwd.append((L.OP_NHWC2NCHW, r))
@@ -344,7 +350,7 @@ class Plan:
 
     def _hrnet(self, x: Act) -> Ten:
         """models/hrnet.py:425-476 as plan primitives; returns the low-resolution logits [T*B, H/4, W/4, nc]."""
-        p, tr = "base_model.", self.base_training
+        p, tr = self.base_prefix, self.base_training
         Wd = branch_widths(self.width)
         x = self.cbr(x, p + "conv1", p + "bn1", 64, 3, 2, True, tr)
         x = self.cbr(x, p + "conv2", p + "bn2", 64, 3, 2, True, tr)

@@ -419,6 +419,34 @@ class Net:
 DEFAULT_CLASS_WEIGHTS = (1.0, 1000.0, 1000.0, 1000.0, 1000.0)   # README.md:85-86
 
 
+class SingleNet(Net):
+    """Single-frame HighResolutionNet with the 'HRNet' model type's last_layer (models/__init__.py:38-46: Conv 1x1 C->C,
+    BN(momentum 0.1), ReLU, Conv 1x1 C->num_classes -- the same structure hrnet.py:333-351 builds, so the layer table is
+    hrnet_table without prefix).  forward(x) = hrnet.py:425-476 on ONE [B,3,H,W] tensor; the caller applies log_softmax
+    (scripts/train_toolpose_segmentation.py:162-163)."""
+
+    def __init__(self, sd, width: int = 48, num_classes: int = 5):
+        self.model_type, self.width, self.nc, self.T = "HRNet", width, num_classes, 1
+        self.optflow, self.depth = False, False
+        self.table = hrnet_table(width, num_classes, "")
+        self.sd = OrderedDict()
+        self.param_names = []
+        for name, shape, kind in self.table:
+            v = sd[name].detach().clone()
+            assert tuple(v.shape) == tuple(shape), (name, v.shape, shape)
+            if kind in ("conv_w", "conv_b", "bn_gamma", "bn_beta"):
+                v.requires_grad_(True)
+                self.param_names.append(name)
+            self.sd[name] = v
+        self.base_training = True
+        self.head_training = True
+
+    def forward(self, x):
+        return self.hrnet(x, p="")
+
+    __call__ = forward
+
+
 def loss_nll(logp, target, class_weights):
     """loss.py:31-43: nn.NLLLoss(weight) -> weighted mean."""
     w = torch.as_tensor(class_weights, dtype=torch.float32)

@@ -151,6 +151,66 @@ def run_case(mf, ref_loss, case):
     print(name, "ok", tuple(y.shape), {k: float(v) for k, v in out.items() if k.startswith("loss_")})
 
 
+SINGLE_CASES = [            # name, B, H, W, mode   (single-frame 'HRNet' model type, models/__init__.py:38-46)
+    ("hrnet_single_train", 2, 64, 96, "train"),
+    ("hrnet_single_eval", 2, 64, 96, "eval"),
+]
+SINGLE_SENTINELS = ["conv1.weight", "layer1.0.conv2.weight", "stage3.1.branches.2.3.conv2.weight", "stage4.0.fuse_layers.0.3.0.weight",
+                    "last_layer.0.weight", "last_layer.1.bias", "last_layer.3.weight", "last_layer.3.bias"]
+
+
+def run_single_case(ref_loss, case):
+    """The reference's single-frame model: HighResolutionNet() with last_layer swapped as get_tooltip_segmentation_model does
+    for model_type 'HRNet' (models/__init__.py:38-46; the pretrained Cityscapes file it loads first does not exist here, the
+    hashed weights stand in), stepped as scripts/train_toolpose_segmentation.py:162-163: log_softmax(model(x)) + get_loss."""
+    import torch.nn as nn
+    name, B, H, W, mode = case
+    hr = sys.modules["hrnet"]
+    net = hr.HighResolutionNet()
+    cin = net.last_layer[0].in_channels
+    net.last_layer = nn.Sequential(nn.Conv2d(cin, cin, kernel_size=1, stride=1, padding=0), hr.BatchNorm2d(cin, momentum=0.1),
+                                   nn.ReLU(inplace=True), nn.Conv2d(cin, 5, kernel_size=1, stride=1, padding=0))
+    table = O.hrnet_table(48, 5, "")
+    assert list(net.state_dict().keys()) == [t[0] for t in table], "state_dict key order/name mismatch"
+    net.load_state_dict(O.hashed_state(table), strict=True)
+    frames, _, _, mask = O.synthetic_clip(name, B, 1, H, W, False, False)
+    x = frames[0]
+    out = {"meta": np.array(["HRNet", "1", "0", "0", str(B), str(H), str(W), mode])}
+    if mode == "eval":
+        net.eval()
+        with torch.no_grad():
+            y = net(x)
+    else:
+        net.train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        opt.zero_grad()
+        y = net(x)
+        logp = torch.nn.functional.log_softmax(y, dim=1)
+        args = SimpleNamespace(class_weights=np.array(O.DEFAULT_CLASS_WEIGHTS), num_classes=5)
+        loss, ld = ref_loss.get_loss(logp, mask, ["nll", "soft_jaccard"], [0.7, 0.3], args)
+        loss.backward()
+        named = dict(net.named_parameters())
+        for s in SINGLE_SENTINELS:
+            gr = named[s].grad
+            out["gradnorm/" + s] = np.float64(gr.double().norm().item())
+            flat = gr.flatten()
+            out["gradsample/" + s] = flat[torch.linspace(0, flat.numel() - 1, 16).long()].numpy().copy()
+        opt.step()
+        for s in SINGLE_SENTINELS:
+            flat = named[s].detach().flatten()
+            out["paramsample/" + s] = flat[torch.linspace(0, flat.numel() - 1, 16).long()].numpy().copy()
+        st = net.state_dict()
+        for b in ("bn1", "last_layer.1"):
+            out["bn_mean/" + b] = st[b + ".running_mean"].numpy().copy()
+            out["bn_var/" + b] = st[b + ".running_var"].numpy().copy()
+            out["bn_count/" + b] = np.int64(st[b + ".num_batches_tracked"].item())
+        for k, v in ld.items():
+            out[k] = np.float64(v)
+    out["logits"] = y.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "ok", tuple(y.shape))
+
+
 METRIC_CASES = [            # (name, B, num_classes, H, W, seed, logit scale)
     ("metrics_b3", 3, 5, 40, 56, 101, 2.0),
     ("metrics_b1", 1, 5, 33, 47, 102, 1.0),
@@ -191,6 +251,10 @@ if __name__ == "__main__":
     if only and all(o.startswith("metrics_") for o in only):
         sys.exit(0)
     mf, ref_loss = import_reference()
+    for c in SINGLE_CASES:
+        if only and c[0] not in only:
+            continue
+        run_single_case(ref_loss, c)
     for c in CASES:
         if only and c[0] not in only:
             continue
