@@ -238,6 +238,10 @@ typedef struct {
     mfc_view mask;           /* same resolution as g (mode 1) */
     mfc_view dst;            /* resolution of the term's source */
     int32_t mask_mode, dtype, N, C, accumulate;
+    int32_t pad_;
+    float* scratch;          /* dst smaller than g (adjoint of an up-sampling): fp32 [N, g.H, dst.W, C] workspace of the
+                              * separable form (a W pass over the high-resolution gradient, then an H pass); NULL selects the
+                              * one-pass gather */
 } mfc_maskadd_desc;
 int mfc_mask_add(const mfc_maskadd_desc* d, void* stream);
 

@@ -495,6 +495,92 @@ __global__ __launch_bounds__(256) void mask_add_kernel(mfc_maskadd_desc d, long 
     *(uint4*)o = Gran<T>::pack(acc);
 }
 
+// Separable form of the same adjoint (the bilinear weights are a product of a row and a column factor):
+//   pass W: tmp[n, h, wl, c]  = sum_ww  Uw[ww -> wl] * (g*m)[n, h, ww, c]      (streams the high-resolution gradient once,
+//                                                                              neighbouring lanes read neighbouring granules)
+//   pass H: dst[n, hl, wl, c] (+)= sum_hh Uh[hh -> hl] * tmp[n, hh, wl, c]
+// tmp is fp32, so the result is rounded once like the one-pass gather.
+template <typename T>
+__global__ __launch_bounds__(256) void mask_add_wpass_kernel(mfc_maskadd_desc d, unsigned total, int Cg) {
+    constexpr int E = Gran<T>::E;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;           // (n, h, wl, granule), granule fastest
+    if (idx >= total) return;
+    const int g = (int)(idx % (unsigned)Cg); unsigned r = idx / (unsigned)Cg;
+    const int wl = (int)(r % (unsigned)d.dst.W); r /= (unsigned)d.dst.W;          // r = n * g.H + h
+    int wlo, whi;
+    adj_range(wl, d.dst.W, d.g.W, wlo, whi);
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    const char* grow = (const char*)d.g.ptr + ((size_t)r * d.g.W * d.g.Cp + d.g.c_off + g * E) * sizeof(T);
+    const char* mrow = d.mask_mode == 1 ? (const char*)d.mask.ptr + ((size_t)r * d.mask.W * d.mask.Cp + d.mask.c_off + g * E) * sizeof(T) : nullptr;
+    for (int ww0 = wlo; ww0 <= whi; ww0 += 4) {
+        uint4 gr[4], mr[4]; float wt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                               // unconditional (clamped) loads, weight 0 outside the footprint
+            const int ww = min(ww0 + q, whi);
+            int w0, w1; float lw;
+            bilin_src(ww, d.dst.W, d.g.W, w0, w1, lw);
+            wt[q] = (ww0 + q <= whi) ? ((w0 == wl ? 1.f - lw : 0.f) + (w1 == wl ? lw : 0.f)) : 0.f;
+            gr[q] = *(const uint4*)(grow + (size_t)ww * d.g.Cp * sizeof(T));
+            if (d.mask_mode == 1) mr[q] = *(const uint4*)(mrow + (size_t)ww * d.mask.Cp * sizeof(T));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float gv[E];
+            Gran<T>::unpack(gr[q], gv);
+            if (d.mask_mode == 1) {
+                float m[E];
+                Gran<T>::unpack(mr[q], m);
+#pragma unroll
+                for (int e = 0; e < E; ++e) gv[e] = m[e] > 0.f ? gv[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += wt[q] * gv[e];
+        }
+    }
+    float* o = d.scratch + (size_t)idx * E;
+#pragma unroll
+    for (int e = 0; e < E; e += 4) *(float4*)(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mask_add_hpass_kernel(mfc_maskadd_desc d, unsigned total, int Cg) {
+    constexpr int E = Gran<T>::E;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;           // (n, hl, wl, granule)
+    if (idx >= total) return;
+    const unsigned rowg = (unsigned)d.dst.W * (unsigned)Cg;          // granules per tmp row
+    const unsigned col = idx % rowg; unsigned r = idx / rowg;
+    const int hl = (int)(r % (unsigned)d.dst.H); const int n = (int)(r / (unsigned)d.dst.H);
+    int hlo, hhi;
+    adj_range(hl, d.dst.H, d.g.H, hlo, hhi);
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    const float* base = d.scratch + ((size_t)n * d.g.H * rowg + col) * E;
+    for (int hh = hlo; hh <= hhi; ++hh) {
+        int h0, h1; float lh;
+        bilin_src(hh, d.dst.H, d.g.H, h0, h1, lh);
+        const float wh = (h0 == hl ? 1.f - lh : 0.f) + (h1 == hl ? lh : 0.f);
+        if (wh == 0.f) continue;
+        const float* p = base + (size_t)hh * rowg * E;
+#pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            const float4 v = *(const float4*)(p + e);
+            acc[e] += wh * v.x; acc[e + 1] += wh * v.y; acc[e + 2] += wh * v.z; acc[e + 3] += wh * v.w;
+        }
+    }
+    const int g = (int)(col % (unsigned)Cg), wl = (int)(col / (unsigned)Cg);
+    char* o = (char*)d.dst.ptr + ((((size_t)n * d.dst.H + hl) * d.dst.W + wl) * d.dst.Cp + d.dst.c_off + g * E) * sizeof(T);
+    if (d.accumulate) {
+        float old[E];
+        Gran<T>::unpack(*(const uint4*)o, old);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += old[e];
+    }
+    *(uint4*)o = Gran<T>::pack(acc);
+}
+
 // same-resolution fast path: linear pixel index, 4 granules in flight per thread
 template <typename T>
 __global__ __launch_bounds__(256) void mask_add_same_kernel(mfc_maskadd_desc d, long total, int Cg) {
@@ -551,6 +637,20 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
         return MFC_OK;
     }
     if (d->g.H < d->dst.H || d->g.W < d->dst.W) return MFC_ERR_UNSUPPORTED;      // the adjoint of an UP-sampling only
+    if (d->scratch) {          // separable two-pass form
+        const long t1 = (long)d->N * d->g.H * d->dst.W * Cg;
+        if (t1 >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;
+        const int b1 = (int)((t1 + 255) / 256), b2 = (int)((total + 255) / 256);
+        if (d->dtype == MFC_BF16) {
+            hipLaunchKernelGGL(mask_add_wpass_kernel<bf16_t>, dim3(b1), dim3(256), 0, st, *d, (unsigned)t1, Cg);
+            hipLaunchKernelGGL(mask_add_hpass_kernel<bf16_t>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg);
+        } else {
+            hipLaunchKernelGGL(mask_add_wpass_kernel<float>, dim3(b1), dim3(256), 0, st, *d, (unsigned)t1, Cg);
+            hipLaunchKernelGGL(mask_add_hpass_kernel<float>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg);
+        }
+        MFC_CHECK_LAUNCH();
+        return MFC_OK;
+    }
     const int ratio = (d->g.H + d->dst.H - 1) / d->dst.H;
     int LS = ratio >= 4 ? 3 : ratio >= 2 ? 2 : 1;                               // column lanes per output granule = 2^LS
     while (LS > 0 && (Cg << LS) > 256) --LS;

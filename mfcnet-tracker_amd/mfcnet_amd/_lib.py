@@ -89,7 +89,7 @@ class BnBwdFinDesc(C.Structure):
 
 class MaskAddDesc(C.Structure):
     _fields_ = [("g", View), ("mask", View), ("dst", View),
-                ("mask_mode", i32), ("dtype", i32), ("N", i32), ("C", i32), ("accumulate", i32)]
+                ("mask_mode", i32), ("dtype", i32), ("N", i32), ("C", i32), ("accumulate", i32), ("pad_", i32), ("scratch", vp)]
 
 
 class HeadDesc(C.Structure):

@@ -532,6 +532,8 @@ class Plan:
                             md.mask = m_in
                         acc = 1 if (s.grad_init and tm.bn is None) else 0
                         md.mask_mode, md.dtype, md.N, md.C, md.accumulate = md_in, self.dtype, out.N, Cs, acc
+                        if not same(tm):        # adjoint of an up-sampling: separable two-pass form, fp32 workspace [N, H, w, C]
+                            md.scratch = self._alloc("act", out.N * out.H * s.W * Cs * 4)
                         self.bwd.append((L.OP_MASK_ADD, md))
                         s.grad_init = True
                         if tm is idt:

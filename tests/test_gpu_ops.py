@@ -293,6 +293,12 @@ def test_mask_add_adjoint_bilinear(M, dtype, hw):
     d.mask_mode, d.dtype, d.N, d.C, d.accumulate = 1, ops.dt_of(tg), N, Cc, 1
     L.call(L.lib.mfc_mask_add, d)
     assert relerr(ops.to_nchw(dst, Cc).cpu() - 1.0, src.grad) < TOL[dtype] * 2
+    if (hs, ws) != (H, W):          # the separable two-pass form (fp32 workspace [N, H, ws, C]) gives the same adjoint
+        dst2 = torch.ones(N, hs, ws, Cc, dtype=dtype, device="cuda")
+        scratch = torch.empty(N * H * ws * Cc, dtype=torch.float32, device="cuda")
+        d.dst, d.scratch = ops.view(dst2), scratch.data_ptr()
+        L.call(L.lib.mfc_mask_add, d)
+        assert relerr(ops.to_nchw(dst2, Cc).cpu() - 1.0, src.grad) < TOL[dtype] * 2
 
 
 @pytest.mark.parametrize("dtype", DT)
