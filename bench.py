@@ -136,6 +136,8 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_ASYNC_PRIO"):            # before the first program run (read when the streams are created)
+        L.lib.mfc_set_flag(16, int(os.environ["MFC_ASYNC_PRIO"]))
     if os.environ.get("MFC_SKIP_KINDS"):            # what-if timing only (results are wrong)
         L.lib.mfc_set_flag(15, int(os.environ["MFC_SKIP_KINDS"]))
     if os.environ.get("MFC_ASYNC_ON_LANE"):

@@ -304,6 +304,9 @@ int mfc_set_lane_streams(int n) {
 }
 static int g_async_n = 1;        // async streams in use (1..MFC_ASYNC_STREAMS; measured: 1 is best, concurrent wgrads fight each other); tuning: mfc_set_flag(10, n)
 int mfc_set_lanes(int on) { g_lanes_on = on; return 0; }
+static int g_async_prio = 0;     // priority of the detached stream: 1 lowest, 0 default, -1 highest (read when the streams are created).  Measured:
+                                 // either non-default priority costs 35 % of the step (526 -> 330 frames/s) -- keep 0; mfc_set_flag(16, v)
+int mfc_set_async_prio(int v) { g_async_prio = v; return 0; }
 static int g_skip_kinds = 0;     // tuning only: bit k set -> records of kind k are skipped (what-if timing); mfc_set_flag(15, mask)
 int mfc_set_skip_kinds(int m) { g_skip_kinds = m; return 0; }
 static int g_async_on_lane = 0;  // 0: detached records on their own stream; k >= 2: on side lane k's stream; tuning: mfc_set_flag(13, k)
@@ -321,7 +324,12 @@ static LaneSet* lanes_for_device() {
         if (hipStreamCreateWithFlags(&L->m, hipStreamNonBlocking) != hipSuccess) return nullptr;
         for (int i = 2; i <= 3; ++i)
             if (hipStreamCreateWithFlags(&L->s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipStreamCreateWithFlags(&L->as[0], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        {   // (a low-priority detached stream looked attractive -- fill only what the critical chain leaves idle -- but see g_async_prio)
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            const int prio = g_async_prio == 0 ? 0 : (g_async_prio > 0 ? lo : hi);
+            if (hipStreamCreateWithPriority(&L->as[0], hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
+        }
         for (int i = 4; i <= MFC_MAX_LANES; ++i)
             if (hipStreamCreateWithFlags(&L->s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
         for (int i = 1; i < MFC_ASYNC_STREAMS; ++i)
