@@ -217,6 +217,15 @@ typedef struct {
     float* bstats;           /* [R][G][2][Cp] */
     const float* bcoef;      /* [G][2][Cp] c1, c2 (apply) */
     int32_t mask_mode, dtype, N, C, images_per_group, accumulate;
+    /* apply only, optional: finalize fused into the apply launch (fin_dgamma set).  Every workgroup first sums the replica
+     * rows of `bstats` itself (c1, c2 into LDS; `bcoef` is then unused) and workgroup 0 writes dgamma / dbeta -- which takes
+     * the tiny dependent mfc_bnbwd_finalize launch (~4 us of launch latency) out of the BatchNorm's backward chain.  For
+     * BatchNorms of at most 128 channels (the redundant prologue grows with C). */
+    float* fin_dgamma;       /* [fin_C] */
+    float* fin_dbeta;        /* [fin_C] */
+    int32_t fin_C, fin_training;
+    float fin_count;
+    int32_t pad_;
 } mfc_bnbwd_desc;
 int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream);
 int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream);

@@ -397,9 +397,87 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long
     }
 }
 
+// apply with the finalize fused in: persistent workgroups; prologue = replica sums -> c1, c2 in LDS (and dgamma / dbeta from
+// workgroup 0); then the same element-wise pass over chunks of 1024 granules
+template <typename T>
+__global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, unsigned total, int Cg, int G, unsigned nchunks) {
+    constexpr int E = Gran<T>::E;
+    constexpr int U = 4;
+    __shared__ float lbc[8 * 2 * 128];               // [g][stat][c] (G <= 8, C <= 128): c1 = mean(g*m), c2 = mean(g*m*yhat)
+    const int Cs = Cg * E, Cp = d.y.Cp;
+    const size_t rstride = (size_t)G * 2 * Cp;
+    for (int i = threadIdx.x; i < G * 2 * Cs; i += 256) {
+        const int c = i % Cs, gs = i / Cs;            // gs = g*2 + stat
+        double s = 0.0;
+        if (c < d.fin_C) s = replica_sum(d.bstats + (size_t)gs * Cp + d.y.c_off + c, rstride);
+        lbc[i] = (float)s;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < d.fin_C; c += 256) {
+            double db = 0.0, dg = 0.0;
+            for (int g = 0; g < G; ++g) { db += (double)lbc[(g * 2 + 0) * Cs + c]; dg += (double)lbc[(g * 2 + 1) * Cs + c]; }
+            d.fin_dgamma[c] = (float)dg; d.fin_dbeta[c] = (float)db;
+        }
+        __syncthreads();
+    }
+    const float inv = d.fin_training ? 1.0f / d.fin_count : 0.f;
+    for (int i = threadIdx.x; i < G * 2 * Cs; i += 256)
+        lbc[i] = d.fin_training ? (float)((double)lbc[i] / (double)d.fin_count) : 0.f;
+    (void)inv;
+    __syncthreads();
+    const unsigned ppg = (unsigned)d.images_per_group * d.y.H * d.y.W;
+    for (unsigned chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const unsigned base = (chunk * 256u) * U + threadIdx.x;
+        uint4 yr[U], gr[U], mr[U]; unsigned pix[U]; int gq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            unsigned idx = base + u * 256u;
+            if (idx >= total) idx = total - 1;
+            pix[u] = idx / (unsigned)Cg; gq[u] = (int)(idx - pix[u] * (unsigned)Cg);
+            yr[u] = ld_lin<T>(d.y, pix[u], d.y.c_off + gq[u] * E);
+            gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
+            if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + u * 256u >= total) break;
+            const int grp = (int)(pix[u] / ppg);
+            const int c = d.y.c_off + gq[u] * E;
+            const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * Cp + c;
+            const float* b1 = lbc + (grp * 2 + 0) * Cs + gq[u] * E;
+            const float* b2 = lbc + (grp * 2 + 1) * Cs + gq[u] * E;
+            float yv[E], gm[E], o[E];
+            Gran<T>::unpack(yr[u], yv); Gran<T>::unpack(gr[u], gm);
+            apply_mask<T>(d, mr[u], yv, cf, gm);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float yh = (yv[e] - cf[2 * Cp + e]) * cf[3 * Cp + e];
+                o[e] = cf[e] * (gm[e] - b1[e] - yh * b2[e]);
+            }
+            *(uint4*)((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(o);
+        }
+    }
+}
+
 extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
     int E; int rc = bnbwd_check(d, E); if (rc < 0) return rc;
-    if (!d->bcoef || !view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W) return MFC_ERR_INVALID_ARG;
+    if (!view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W) return MFC_ERR_INVALID_ARG;
+    if (d->fin_dgamma) {       // finalize fused into this launch
+        const int G = d->N / d->images_per_group;
+        if (!d->bstats || !d->fin_dbeta || d->fin_C <= 0 || d->fin_C > d->C || d->C > 128 || G > 8 || d->fin_count <= 0.f) return MFC_ERR_INVALID_ARG;
+        const int Cgf = d->C / E;
+        const long tot = (long)d->N * d->y.H * d->y.W * Cgf;
+        if (tot >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;
+        const unsigned nchunks = (unsigned)((tot + 1023) / 1024);
+        const int grid = nchunks < 1024u ? (int)nchunks : 1024;
+        hipStream_t s2 = (hipStream_t)stream;
+        if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_apply_fin_kernel<bf16_t>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, nchunks);
+        else hipLaunchKernelGGL(bnbwd_apply_fin_kernel<float>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, nchunks);
+        MFC_CHECK_LAUNCH();
+        return MFC_OK;
+    }
+    if (!d->bcoef) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     const long total = (long)d->N * d->y.H * d->y.W * Cg;
     if (total >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;      // kernels index granules with 32 bits

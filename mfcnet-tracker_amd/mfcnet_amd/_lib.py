@@ -79,7 +79,8 @@ class CombineDesc(C.Structure):
 
 class BnBwdDesc(C.Structure):
     _fields_ = [("g", View), ("y", View), ("mask", View), ("dy", View), ("bstats", vp), ("bcoef", vp),
-                ("mask_mode", i32), ("dtype", i32), ("N", i32), ("C", i32), ("images_per_group", i32), ("accumulate", i32)]
+                ("mask_mode", i32), ("dtype", i32), ("N", i32), ("C", i32), ("images_per_group", i32), ("accumulate", i32),
+                ("fin_dgamma", vp), ("fin_dbeta", vp), ("fin_C", i32), ("fin_training", i32), ("fin_count", f32), ("pad_", i32)]
 
 
 class BnBwdFinDesc(C.Structure):

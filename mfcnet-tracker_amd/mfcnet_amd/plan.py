@@ -144,6 +144,7 @@ class Plan:
         self.need_backward = need_backward
         self.device = device
         self.fuse_bn = model.fuse_bn
+        self.fuse_fin = getattr(model, "fuse_bn_finalize", True)     # BN-backward finalize inside the apply launch (C <= 128)
         self.lanes = getattr(model, "parallel_branches", True)      # branch-parallel lanes of the program (include/mfcnet_hip.h, mfc_op.lane)
         self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc")}
         self._build()                       # dry pass: sizes
@@ -461,13 +462,19 @@ class Plan:
             d.mask_mode, d.dtype, d.N, d.C, d.images_per_group, d.accumulate = mode, self.dtype, y.N, C, y.ipg, acc
             return d
         self.bwd.append((L.OP_BNBWD_REDUCE, desc(g_view, mask_mode, mask_view, gm_view, gm_acc)))
-        self.bwd.append((L.OP_BNBWD_FIN, L.BnBwdFinDesc(bn.bstats, bn.bcoef, self.gptr(bn.name + ".weight"),
-                                                        self.gptr(bn.name + ".bias"), bn.C, bn.Cp, bn.G,
-                                                        1 if bn.training else 0, bn.count)))
+        fused_fin = self.fuse_fin and C <= 128 and bn.C <= C and bn.G <= 8
+        if not fused_fin:
+            self.bwd.append((L.OP_BNBWD_FIN, L.BnBwdFinDesc(bn.bstats, bn.bcoef, self.gptr(bn.name + ".weight"),
+                                                            self.gptr(bn.name + ".bias"), bn.C, bn.Cp, bn.G,
+                                                            1 if bn.training else 0, bn.count)))
         if gm_view is not None and not gm_acc:
-            self.bwd.append((L.OP_BNBWD_APPLY, desc(gm_view, 0, None, dy_view, 0)))
+            ad = desc(gm_view, 0, None, dy_view, 0)
         else:
-            self.bwd.append((L.OP_BNBWD_APPLY, desc(g_view, mask_mode, mask_view, dy_view, 0)))
+            ad = desc(g_view, mask_mode, mask_view, dy_view, 0)
+        if fused_fin:       # the finalize rides in the apply launch (one dependent launch less per BatchNorm)
+            ad.fin_dgamma, ad.fin_dbeta = self.gptr(bn.name + ".weight"), self.gptr(bn.name + ".bias")
+            ad.fin_C, ad.fin_training, ad.fin_count = bn.C, 1 if bn.training else 0, bn.count
+        self.bwd.append((L.OP_BNBWD_APPLY, ad))
 
     def _emit_backward(self):
         E, Cs = self.E, None

@@ -266,6 +266,15 @@ def test_bn_backward(M, dtype, mode):
     L.call(L.lib.mfc_bnbwd_apply, d)
     assert relerr(ops.to_nchw(dy, Cc).cpu(), y.grad) < tol
     assert relerr(dgam.cpu(), gamma.grad) < tol and relerr(dbet.cpu(), beta.grad) < tol
+    # the finalize fused into the apply launch (every workgroup sums the replicas itself) gives the same dy and parameter gradients
+    dy3 = torch.zeros_like(ty)
+    dgam3, dbet3 = torch.full_like(dgam, 9.0), torch.full_like(dbet, 9.0)
+    dfu = L.BnBwdDesc.from_buffer_copy(d)
+    dfu.dy, dfu.bcoef = ops.view(dy3), 0
+    dfu.fin_dgamma, dfu.fin_dbeta, dfu.fin_C, dfu.fin_training, dfu.fin_count = dgam3.data_ptr(), dbet3.data_ptr(), Cc, 1, float(ipg * H * W)
+    L.call(L.lib.mfc_bnbwd_apply, dfu)
+    assert relerr(ops.to_nchw(dy3, Cc).cpu(), y.grad) < tol
+    assert relerr(dgam3.cpu(), dgam.cpu()) < 1e-5 and relerr(dbet3.cpu(), dbet.cpu()) < 1e-5
     # ... and the apply pass may read g*m back instead of g and the mask
     dy2 = torch.zeros_like(ty)
     da = L.BnBwdDesc.from_buffer_copy(d)
