@@ -20,7 +20,9 @@ int mfc_conv_set_force_mt(int v);
 int mfc_conv_set_grid(int v);
 int mfc_conv_set_ablate(int v);
 static int g_wgrad_ablate = 0;
-static int g_wgrad_blocks = 512;     // target workgroups per wave-kernel launch (S = blocks / Y); tuning: mfc_set_flag(11, n)
+static int g_wgrad_blocks = 256;     // target workgroups per wave-kernel launch (S = blocks / Y).  Alone, 512 (2 per CU) is fastest; in the
+                                     // step the launches run on the detached stream next to the critical chain, and 1 per CU leaves that
+                                     // chain half of every CU (measured 541 vs 529 frames/s); tuning: mfc_set_flag(11, n)
 int mfc_conv_set_lds_kb(int v);
 int mfc_conv_set_ybfast(int v);
 int mfc_set_lanes(int on);
@@ -46,7 +48,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 14) return mfc_set_own_main(value);
     if (id == 15) return mfc_set_skip_kinds(value);
     if (id == 16) return mfc_set_async_prio(value);
-    if (id == 11) { g_wgrad_blocks = value > 0 ? value : 512; return 0; }
+    if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
 
@@ -945,7 +947,7 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) 
     if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
     const int Y = (f.TA / TAA) * f.co_blocks * f.ci_blocks;
     int S = d->splits;
-    if (S <= 0) S = ceil_div(g_wgrad_blocks, Y);      // 2 workgroups per CU (the flush is a plain store of the partial sums: extra workgroups are cheap)
+    if (S <= 0) S = ceil_div(g_wgrad_blocks, Y);
     if (S * 4 > f.ntiles) S = ceil_div(f.ntiles, 4);
     if (S < 1) S = 1;
     f.splits = S;
