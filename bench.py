@@ -114,6 +114,8 @@ def main():
     torch.manual_seed(1234)                                    # identical initial weights on every rank
     model = mfc.HRNetMultiLarge(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype=args.dtype)
     model = model.to(device).train()
+    if os.environ.get("MFC_BATCH_WGRAD"):          # tuning: 0 = one launch per weight gradient
+        model.batch_wgrad = os.environ["MFC_BATCH_WGRAD"] != "0"
     opt = mfc.FlatAdam(model, lr=1e-4)
     frames, mask = synth(B, T, H, W, nc, 42 + 2000 + rank, device)
 
@@ -136,6 +138,8 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_CONV_GRID"):             # before the plan is built (sizes nothing, but the layouts are queried then)
+        L.lib.mfc_set_flag(4, int(os.environ["MFC_CONV_GRID"]))
     if os.environ.get("MFC_ASYNC_PRIO"):            # before the first program run (read when the streams are created)
         L.lib.mfc_set_flag(16, int(os.environ["MFC_ASYNC_PRIO"]))
     if os.environ.get("MFC_SKIP_KINDS"):            # what-if timing only (results are wrong)

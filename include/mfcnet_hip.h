@@ -140,9 +140,16 @@ typedef struct {
     int32_t in_relu, images_per_group;
     int32_t TH, TW;
     int32_t splits;          /* pixel splits (= parts); 0 = choose */
+    int32_t batch;           /* 0/1: alone.  n > 1: one of n gradients of identical geometry launched together by
+                              * mfc_conv2d_wgrad_batch (each gets 1/n of the workgroups: fewer, longer-running workgroups pay the
+                              * per-workgroup prologue / reduction / partial-sum store n times less often) */
+    int32_t pad_;
 } mfc_wgrad_desc;
 int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream);
-int mfc_conv2d_wgrad_parts(const mfc_wgrad_desc* d);      /* > 0: slices written; < 0: error */
+int mfc_conv2d_wgrad_parts(const mfc_wgrad_desc* d);      /* > 0: slices written (depends on `batch`); < 0: error */
+/* n <= 8 descriptors that differ only in x / dy / dwp / in_coef / in_relu, each with batch = n; bf16 3x3 / 11x11 only
+ * (MFC_ERR_UNSUPPORTED otherwise -- launch them one by one) */
+int mfc_conv2d_wgrad_batch(const mfc_wgrad_desc* descs, int32_t n, void* stream);
 
 typedef struct {
     uint64_t src;            /* const float* packed partial sums [nparts][TA*TB][Co16][Ci16] */
@@ -336,7 +343,8 @@ typedef enum {
     MFC_OP_CONV = 1, MFC_OP_WGRAD = 2, MFC_OP_BNFIN = 3, MFC_OP_COMBINE = 4, MFC_OP_BNBWD_REDUCE = 5,
     MFC_OP_BNBWD_FIN = 6, MFC_OP_BNBWD_APPLY = 7, MFC_OP_MASK_ADD = 8, MFC_OP_HEAD_FWD = 9, MFC_OP_HEAD_BWD = 10,
     MFC_OP_BIAS_GRAD = 11, MFC_OP_MEMSET = 12, MFC_OP_PACK = 13, MFC_OP_UNPACK = 14, MFC_OP_NCHW2NHWC = 15,
-    MFC_OP_NHWC2NCHW = 16
+    MFC_OP_NHWC2NCHW = 16,
+    MFC_OP_WGRAD_BATCH = 17      /* raw.a = HOST pointer to an mfc_wgrad_desc array (kept alive by the caller), raw.i[0] = n */
 } mfc_op_kind;
 
 #define MFC_LANE_ASYNC 0x100

@@ -505,8 +505,17 @@ struct WgradW {
     int ablate;      // tuning only: 1 skip global loads, 2 skip LDS staging stores, 4 skip LDS reads + MFMAs, 8 skip reduction + atomics
 };
 
+// Up to 8 weight gradients of IDENTICAL geometry share one launch (mfc_conv2d_wgrad_batch): the workgroups are dealt to the
+// problems round-robin, so each problem's pixel axis is split over 1/n of the grid and the per-workgroup fixed costs
+// (prologue, LDS tree reduction, partial-sum store) are paid once per n times more pixels.
+#define MFC_WGRAD_MAXBATCH 8
+struct WgradBatch {
+    const char* x[MFC_WGRAD_MAXBATCH]; const char* dy[MFC_WGRAD_MAXBATCH]; float* dwp[MFC_WGRAD_MAXBATCH];
+    const float* coef[MFC_WGRAD_MAXBATCH]; int relu[MFC_WGRAD_MAXBATCH]; int n;
+};
+
 template <int TAA, int TB, int WCO, int WCI, int XP>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p, WgradBatch tb) {
     typedef bf16_t T;
     constexpr int E = 8;
     constexpr int DP = 3;
@@ -518,7 +527,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p) {
     char* wbase = smem + wave * p.wave_bytes;
     // 1-D grid, weight block fastest, XCD-contiguous (see conv_wgrad_fast_kernel): co-scheduled re-reads hit the XCD's L2
     const int Ytot = (p.TA / TAA) * p.co_blocks * p.ci_blocks;
-    const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    if (tb.n > 1) {             // this workgroup's problem (wave-uniform: scalar loads from the kernel arguments)
+        const int prob = Lb % tb.n;
+        Lb /= tb.n;
+        p.x = tb.x[prob]; p.dy = tb.dy[prob]; p.dwp = tb.dwp[prob]; p.in_coef = tb.coef[prob]; p.in_relu = tb.relu[prob];
+    }
     int y = Lb % Ytot;
     const int bsplit = Lb / Ytot;
     const int ib = y % p.ci_blocks; y /= p.ci_blocks;
@@ -859,18 +873,18 @@ static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) 
 }
 
 template <int TAA, int TB, int WCO, int WCI, int XP>
-static int wgrad_wave_launch(const WgradW& f, size_t lds, int Y, hipStream_t st) {
+static int wgrad_wave_launch(const WgradW& f, const WgradBatch& tb, size_t lds, int Y, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on) {
-        const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB;
-        const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
+        const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB * tb.n;
+        const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0 * tb.n;
         mfc_prof_before(st, 1 * 64 + 32 + 16 + (TB == 3 ? 0 : 1), flops, bytes);
     }
-    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP>), dim3(f.splits * Y), dim3(256), lds, st, f);
+    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP>), dim3(f.splits * Y * tb.n), dim3(256), lds, st, f, tb);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -890,7 +904,7 @@ static void choose_subtile(int Hl, int Wl, int& TH, int& TW, int max_patch = 0) 
     TH = bh; TW = bw;
 }
 
-static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) {
+static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only, const mfc_wgrad_desc* batch = nullptr, int nbatch = 1) {
     if (d->dtype != MFC_BF16 || !g_wgrad_use_tr || g_wgrad_ksplit == 2) return MFC_ERR_UNSUPPORTED;
     if (d->TB != 3 && d->TB != 11) return MFC_ERR_UNSUPPORTED;
     WgradW f;
@@ -943,19 +957,30 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) 
     const size_t need = (size_t)2 * TAA * d->TB * WCO * WCI * 1024;      // tree reduction scratch (2 dumping waves)
     if (stage < need) stage = need;
     f.off_tab = (int)stage; f.off_coef = f.off_tab + 32 * 4;
-    const size_t lds = (size_t)f.off_coef + (d->in_coef ? (size_t)f.G * 2 * f.gx * 8 * 4 : 0);
+    bool any_coef = d->in_coef != nullptr;
+    for (int i = 0; batch && i < nbatch; ++i) any_coef = any_coef || batch[i].in_coef != nullptr;
+    const size_t lds = (size_t)f.off_coef + (any_coef ? (size_t)f.G * 2 * f.gx * 8 * 4 : 0);
     if (lds > 80 * 1024) return MFC_ERR_UNSUPPORTED;
     const int Y = (f.TA / TAA) * f.co_blocks * f.ci_blocks;
     int S = d->splits;
-    if (S <= 0) S = ceil_div(g_wgrad_blocks, Y);
+    const int nb = d->batch > 1 ? d->batch : 1;      // problems sharing the launch: each gets 1/nb of the workgroups
+    if (nb > MFC_WGRAD_MAXBATCH || (batch && nbatch != nb)) return MFC_ERR_INVALID_ARG;
+    if (S <= 0) S = ceil_div(g_wgrad_blocks, Y * nb);
     if (S * 4 > f.ntiles) S = ceil_div(f.ntiles, 4);
     if (S < 1) S = 1;
     f.splits = S;
     f.slice = d->TA * d->TB * f.Co16 * f.Ci16;
     if (parts_only) { *parts_only = S; return MFC_OK; }
     f.ablate = g_wgrad_ablate;
-    if (alltaps) return wgrad_wave_launch<3, 3, 2, 2, 4>(f, lds, Y, st);
-#define WGW(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return nxp <= 4 ? wgrad_wave_launch<1, tb, a_, b_, 4>(f, lds, Y, st) : wgrad_wave_launch<1, tb, a_, b_, 7>(f, lds, Y, st);
+    if (nb > 1 && !batch) return MFC_ERR_INVALID_ARG;          // a batched descriptor must come through mfc_conv2d_wgrad_batch
+    WgradBatch wb;
+    wb.n = nb;
+    for (int i = 0; i < MFC_WGRAD_MAXBATCH; ++i) {
+        const mfc_wgrad_desc* q = (batch && i < nb) ? &batch[i] : d;
+        wb.x[i] = (const char*)q->x; wb.dy[i] = (const char*)q->dy; wb.dwp[i] = q->dwp; wb.coef[i] = q->in_coef; wb.relu[i] = q->in_relu;
+    }
+    if (alltaps) return wgrad_wave_launch<3, 3, 2, 2, 4>(f, wb, lds, Y, st);
+#define WGW(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return nxp <= 4 ? wgrad_wave_launch<1, tb, a_, b_, 4>(f, wb, lds, Y, st) : wgrad_wave_launch<1, tb, a_, b_, 7>(f, wb, lds, Y, st);
     WGW(3, 3, 3) WGW(3, 3, 2) WGW(3, 3, 1) WGW(3, 2, 3) WGW(3, 2, 2) WGW(3, 2, 1) WGW(3, 1, 3) WGW(3, 1, 2) WGW(3, 1, 1)
     WGW(11, 1, 2) WGW(11, 1, 1)
 #undef WGW
@@ -970,6 +995,7 @@ static int wgrad_any(const mfc_wgrad_desc* d, void* stream, int* parts_only) {
     {
         int rcf = wgrad_wave(d, (hipStream_t)stream, parts_only);
         if (rcf != MFC_ERR_UNSUPPORTED) return rcf;
+        if (d->batch > 1) return MFC_ERR_UNSUPPORTED;       // only the wave-private kernel takes batches
         rcf = wgrad_fast(d, (hipStream_t)stream, parts_only);
         if (rcf != MFC_ERR_UNSUPPORTED) return rcf;
     }
@@ -1036,4 +1062,24 @@ extern "C" int mfc_conv2d_wgrad_parts(const mfc_wgrad_desc* d) {
     int parts = 0;
     const int rc = wgrad_any(&t, nullptr, &parts);
     return rc < 0 ? rc : parts;
+}
+
+// n weight gradients of identical geometry (everything but x / dy / dwp / in_coef / in_relu) in one launch; every descriptor
+// carries batch = n and the same `splits`.  MFC_ERR_UNSUPPORTED when the geometry is not served by the wave-private kernel.
+extern "C" int mfc_conv2d_wgrad_batch(const mfc_wgrad_desc* descs, int32_t n, void* stream) {
+    if (!descs || n < 1 || n > MFC_WGRAD_MAXBATCH) return MFC_ERR_INVALID_ARG;
+    if (n == 1 && descs[0].batch <= 1) return wgrad_any(&descs[0], stream, nullptr);
+    const mfc_wgrad_desc& a = descs[0];
+    for (int i = 0; i < n; ++i) {
+        const mfc_wgrad_desc& b = descs[i];
+        if (!b.x || !b.dy || !b.dwp || b.batch != n) return MFC_ERR_INVALID_ARG;
+        if (b.dtype != a.dtype || b.N != a.N || b.Hin != a.Hin || b.Win != a.Win || b.Cin_p != a.Cin_p || b.Cin != a.Cin ||
+            b.Hout != a.Hout || b.Wout != a.Wout || b.Cout_p != a.Cout_p || b.Cout != a.Cout || b.TA != a.TA || b.TB != a.TB ||
+            b.dh0 != a.dh0 || b.dw0 != a.dw0 || b.in_stride != a.in_stride || b.images_per_group != a.images_per_group ||
+            b.splits != a.splits)
+            return MFC_ERR_INVALID_ARG;
+    }
+    if (a.dtype != MFC_BF16) return MFC_ERR_UNSUPPORTED;
+    if (a.Cin_p % 8 || a.Cout_p % 8 || a.Cin > a.Cin_p || a.Cout > a.Cout_p || a.N <= 0 || a.images_per_group <= 0 || a.N % a.images_per_group) return MFC_ERR_INVALID_ARG;
+    return wgrad_wave(&a, (hipStream_t)stream, nullptr, descs, n);
 }

@@ -246,6 +246,7 @@ static int run_one(const mfc_op& o, void* stream) {
     switch (o.kind) {
         case MFC_OP_CONV: return mfc_conv2d_fwd(&o.u.conv, stream);
         case MFC_OP_WGRAD: return mfc_conv2d_wgrad(&o.u.wgrad, stream);
+        case MFC_OP_WGRAD_BATCH: return mfc_conv2d_wgrad_batch((const mfc_wgrad_desc*)o.u.raw.a, o.u.raw.i[0], stream);
         case MFC_OP_BNFIN: return mfc_bn_finalize(&o.u.bnfin, stream);
         case MFC_OP_COMBINE: return mfc_combine_fwd(&o.u.combine, stream);
         case MFC_OP_BNBWD_REDUCE: return mfc_bnbwd_reduce(&o.u.bnbwd, stream);

@@ -23,6 +23,8 @@ STAT_REPLICAS = 32
 OP_CONV, OP_WGRAD, OP_BNFIN, OP_COMBINE, OP_BNBWD_REDUCE, OP_BNBWD_FIN, OP_BNBWD_APPLY, OP_MASK_ADD = range(1, 9)
 LANE_ASYNC = 0x100
 OP_HEAD_FWD, OP_HEAD_BWD, OP_BIAS_GRAD, OP_MEMSET, OP_PACK, OP_UNPACK, OP_NCHW2NHWC, OP_NHWC2NCHW = range(9, 17)
+OP_WGRAD_BATCH = 17
+WGRAD_MAXBATCH = 8
 
 i32, u64, f32, vp = C.c_int32, C.c_uint64, C.c_float, C.c_void_p
 
@@ -54,7 +56,7 @@ class WgradDesc(C.Structure):
                 ("dtype", i32), ("N", i32), ("Hin", i32), ("Win", i32), ("Cin_p", i32), ("Cin", i32),
                 ("Hout", i32), ("Wout", i32), ("Cout_p", i32), ("Cout", i32),
                 ("TA", i32), ("TB", i32), ("dh0", i32), ("dw0", i32), ("in_stride", i32),
-                ("in_relu", i32), ("images_per_group", i32), ("TH", i32), ("TW", i32), ("splits", i32)]
+                ("in_relu", i32), ("images_per_group", i32), ("TH", i32), ("TW", i32), ("splits", i32), ("batch", i32), ("pad_", i32)]
 
 
 class UnpackJob(C.Structure):
@@ -127,7 +129,7 @@ class Op(C.Structure):
 
 
 # every symbol include/mfcnet_hip.h declares
-EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_conv2d_wgrad_parts", "mfc_unpack_wgrad",
+EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_conv2d_wgrad_parts", "mfc_conv2d_wgrad_batch", "mfc_unpack_wgrad",
            "mfc_bn_finalize", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd", "mfc_confusion_counts", "mfc_adam_step", "mfc_program_run", "mfc_program_profile", "mfc_graph_capture", "mfc_graph_launch", "mfc_graph_destroy",
@@ -169,6 +171,7 @@ def _load():
         getattr(lib, name).argtypes = [vp, vp]
     lib.mfc_conv2d_lds_bytes.argtypes = [vp]
     lib.mfc_conv2d_wgrad_parts.argtypes = [vp]
+    lib.mfc_conv2d_wgrad_batch.argtypes = [vp, i32, vp]
     lib.mfc_conv2d_layout.argtypes = [vp, vp]
     lib.mfc_set_flag.argtypes = [i32, i32]
     lib.mfc_prof_enable.argtypes = [i32]

@@ -103,6 +103,8 @@ class ConvInfo:
     dgrad: List = field(default_factory=list)     # data-gradient launch descriptors (1 for stride 1, 4 parity classes for stride 2)
     dwp: int = 0
     wg: Optional[object] = None                   # weight-gradient launch descriptor (x / dy pointers filled at backward emission)
+    slice_bytes: int = 0                          # one partial-sum slice of the packed gradient image
+    unpack: Optional[dict] = None                 # unpack job fields (source / slice count are set with the launch)
 
 
 class _Recs(list):
@@ -144,6 +146,9 @@ class Plan:
         self.need_backward = need_backward
         self.device = device
         self.fuse_bn = model.fuse_bn
+        # weight gradients of identical geometry can share launches (mfc_conv2d_wgrad_batch).  Measured on the W32 step: 3 % SLOWER
+        # (533 vs 545 frames/s) -- deferring a branch's eight gradients to one launch starves the detached stream -- so off by default
+        self.batch_wgrad = getattr(model, "batch_wgrad", False)
         self.fuse_fin = getattr(model, "fuse_bn_finalize", True)     # BN-backward finalize inside the apply launch (C <= 128)
         self.lanes = getattr(model, "parallel_branches", True)      # branch-parallel lanes of the program (include/mfcnet_hip.h, mfc_op.lane)
         self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc")}
@@ -235,12 +240,58 @@ class Plan:
             # the unpack job adds the slices up
             ci.wg = L.WgradDesc(16, 16, 16, in_coef, self.dtype, xt.N, xt.H, xt.W, xt.Cp, xt.C, y.H, y.W, y.Cp, cout, k, k, -pad, -pad,
                                 stride, in_relu, xt.ipg, 0, 0, 0)
-            parts = L.wgrad_parts(ci.wg)
-            ci.dwp = self._alloc("dwp", parts * k * k * Co16 * Ci16 * 4)
-            ci.wg.dwp = ci.dwp
-            self.unpack_jobs.append(dict(src=ci.dwp, dst=self.gptr(wname), Cout=cout, Cin=cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16,
-                                         nparts=parts))
+            ci.slice_bytes = k * k * Co16 * Ci16 * 4
+            ci.unpack = dict(dst=self.gptr(wname), Cout=cout, Cin=cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16)
+            # (the partial-sum buffer is sized when the launch is emitted: gradients of identical geometry share launches,
+            #  and the number of slices depends on how many share one -- see _flush_wgrads)
         return ci
+
+    # ------------------------------------------------------------------ weight-gradient launches
+    def _queue_wgrad(self, ci: ConvInfo):
+        """Weight gradients are detached work (nothing reads them before the final unpack), so those of identical geometry are
+        collected and launched together, up to 8 per launch (mfc_conv2d_wgrad_batch): the 8 3x3 convolutions of a module
+        branch become ONE launch whose workgroups each walk 8x more pixels of one problem."""
+        w = ci.wg
+        key = (self.cur_lane, w.dtype, w.N, w.Hin, w.Win, w.Cin_p, w.Cin, w.Hout, w.Wout, w.Cout_p, w.Cout, w.TA, w.TB, w.dh0, w.dw0,
+               w.in_stride, w.images_per_group)
+        lst = self._wg_pending.setdefault(key, [])
+        lst.append(ci)
+        if len(lst) == L.WGRAD_MAXBATCH or not self.batch_wgrad:
+            self._flush_wgrads(key)
+
+    def _flush_wgrads(self, key=None):
+        keys = [key] if key is not None else list(self._wg_pending)
+        for kk in keys:
+            lst = self._wg_pending.pop(kk, [])
+            if not lst:
+                continue
+            n = len(lst)
+            parts = -1
+            if n > 1:
+                lst[0].wg.batch = n
+                parts = L.lib.mfc_conv2d_wgrad_parts(C.byref(lst[0].wg))       # < 0: this geometry is not batchable
+            groups = [lst] if parts > 0 else [[ci] for ci in lst]
+            for grp in groups:
+                m = len(grp)
+                for ci in grp:
+                    ci.wg.batch = m if m > 1 else 0
+                pr = L.wgrad_parts(grp[0].wg)
+                for ci in grp:
+                    ci.wg.splits = pr if m > 1 else 0
+                    ci.dwp = self._alloc("dwp", pr * ci.slice_bytes)
+                    ci.wg.dwp = ci.dwp
+                    self.unpack_jobs.append(dict(src=ci.dwp, nparts=pr, **ci.unpack))
+                if m == 1:
+                    self.bwd.append((L.OP_WGRAD, grp[0].wg))
+                else:
+                    arr = (L.WgradDesc * m)(*[ci.wg for ci in grp])
+                    self._wg_arrays.append(arr)                                 # the record holds a HOST pointer to this array
+                    r = L.RawOp(C.addressof(arr), 0, 0, 0)
+                    r.i[0] = m
+                    self.bwd.append((L.OP_WGRAD_BATCH, r))
+                if self.lanes:      # detached: nothing reads the partial sums before the final unpack
+                    k_, d_, ln_ = self.bwd[-1]
+                    self.bwd[-1] = (k_, d_, ln_ | L.LANE_ASYNC)
 
     @staticmethod
     def _s2_class(k, pad, ph):
@@ -478,8 +529,13 @@ class Plan:
 
     def _emit_backward(self):
         E, Cs = self.E, None
+        self._wg_pending, self._wg_arrays = {}, []
         for op, lane in zip(reversed(self.ops), reversed(self.ops.lanes)):
             kind = op[0]
+            if lane != self.cur_lane:
+                # leaving a lane: what is still queued there is launched first (from the lane that produced its inputs; after a
+                # parallel section the first serial record joins the side lanes before anything runs)
+                self._flush_wgrads()
             self.cur_lane = lane
             if kind == "out":
                 o = op[1]
@@ -566,10 +622,7 @@ class Plan:
                 xt = x.t
                 k, s, pad = ci.k, ci.stride, ci.pad
                 ci.wg.x, ci.wg.dy = xt.ptr, dy.ptr
-                self.bwd.append((L.OP_WGRAD, ci.wg))
-                if self.lanes:      # detached: nothing reads the partial sums before the final unpack
-                    k_, d_, ln_ = self.bwd[-1]
-                    self.bwd[-1] = (k_, d_, ln_ | L.LANE_ASYNC)
+                self._queue_wgrad(ci)
                 if ci.bias:
                     r = L.RawOp(dy.ptr, self.gptr(ci.bias), 0, y.N * y.H * y.W)
                     r.i[0:3] = [self.dtype, y.Cp, ci.cout]
@@ -584,6 +637,7 @@ class Plan:
                     if x.bn is not None:
                         xt.virtual_consumed, xt.virtual_relu = True, x.relu
 
+        self._flush_wgrads()
         self.cur_lane = 0
 
     # ------------------------------------------------------------------ program arrays

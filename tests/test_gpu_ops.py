@@ -450,6 +450,41 @@ def test_loss_global_batch_split(M):
     assert relerr(torch.cat(grads), logits.grad) < 1e-4
 
 
+def test_wgrad_batch_matches_single_launches(M):
+    """mfc_conv2d_wgrad_batch: n weight gradients of identical geometry in one launch (one with the fused input transform)
+    equal the n single launches -- both write deterministic partial-sum slices, so the totals agree to fp32 summation order."""
+    _, L, ops = M
+    dtype = torch.bfloat16
+    N, Cin, Cout, k, H, W = 6, 32, 32, 3, 24, 40
+    n = 3
+    xs = [rnd(dtype, N, Cin, H, W, seed=60 + i) for i in range(n)]
+    dys = [rnd(dtype, N, Cout, H, W, seed=70 + i) for i in range(n)]
+    coef = torch.randn(3, 4, Cin).cuda()
+    tx = [ops.to_nhwc(x, dtype) for x in xs]
+    tdy = [ops.to_nhwc(d, dtype) for d in dys]
+    Co16, Ci16 = ops.rup(Cout, 16), ops.rup(Cin, 16)
+    singles = [ops.conv2d_wgrad(tx[i], tdy[i], Cout, Cin, k, 1, in_coef=coef if i == 1 else None, in_relu=(i == 1), ipg=2) for i in range(n)]
+    descs = (L.WgradDesc * n)()
+    bufs, outs = [], []
+    for i in range(n):
+        descs[i] = L.WgradDesc(tx[i].data_ptr(), tdy[i].data_ptr(), 0, coef.data_ptr() if i == 1 else 0, L.BF16, N, H, W, tx[i].shape[3], Cin,
+                               H, W, tdy[i].shape[3], Cout, k, k, -1, -1, 1, 1 if i == 1 else 0, 2, 0, 0, 0, n, 0)
+    parts = L.wgrad_parts(descs[0])
+    for i in range(n):
+        buf = torch.zeros(parts * k * k * Co16 * Ci16, dtype=torch.float32, device="cuda")
+        bufs.append(buf)
+        descs[i].dwp, descs[i].splits = buf.data_ptr(), parts
+    L.check(L.lib.mfc_conv2d_wgrad_batch(descs, n, L.stream_ptr()), "mfc_conv2d_wgrad_batch")
+    for i in range(n):
+        dw = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device="cuda")
+        ops._run_jobs([dict(src=bufs[i].data_ptr(), dst=dw.data_ptr(), Cout=Cout, Cin=Cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16, nparts=parts)],
+                      L.UnpackJob, L.lib.mfc_unpack_wgrad)
+        assert relerr(dw.cpu(), singles[i].cpu()) < 1e-5, i
+    # mismatching geometry / batch counts are rejected
+    descs[1].Hin += 1
+    assert L.lib.mfc_conv2d_wgrad_batch(descs, n, L.stream_ptr()) == -1
+
+
 def test_adam_matches_torch(M):
     _, L, ops = M
     n = 10007
