@@ -27,6 +27,9 @@ __device__ inline unsigned bf16_bits(float f) {
     bf16_t b = (bf16_t)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return (unsigned)__builtin_bit_cast(unsigned short, b);
 }
+// ReLU that keeps NaN (torch.relu(nan) = nan; v_max_f32 would return the other operand and silently swallow a diverged value,
+// which the reference's `math.isnan(loss.item())` check, src/engine.py:67, relies on seeing)
+__device__ inline float relu_nan(float t, float floor = 0.f) { return t < floor ? floor : t; }
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ inline unsigned pack_bf16x2(float lo, float hi) {      // one v_cvt_pk_bf16_f32

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
                             float t = f[e] * sc[e] + sh[e];
-                            f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
+                            f[e] = p.in_relu ? relu_nan(t) : t;
                         }
                         v = Gran<T>::pack(f);
                     }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
 #pragma unroll
                             for (int e = 0; e < E; ++e) {
                                 float t = f[e] * sc[e] + sh[e];
-                                f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
+                                f[e] = p.in_relu ? relu_nan(t) : t;
                             }
                             v = Gran<T>::pack(f);
                         }
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_fast_kernel(Wgrad
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
                             float t = f[e] * cf[e] + cf[p.gx * 8 + e];
-                            f[e] = p.in_relu ? fmaxf(t, 0.f) : t;
+                            f[e] = p.in_relu ? relu_nan(t) : t;
                         }
                         v = Gran<T>::pack(f);
                     }
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p, Wgrad
                 float f[E];
                 Gran<T>::unpack(v, f);
 #pragma unroll
-                for (int e = 0; e < E; ++e) f[e] = fmaxf(f[e] * cf[e] + cf[p.gx * 8 + e], relu_floor);
+                for (int e = 0; e < E; ++e) f[e] = relu_nan(f[e] * cf[e] + cf[p.gx * 8 + e], relu_floor);
                 v = Gran<T>::pack(f);
             }
             if (!interior && !(xmask & (1u << i))) v = make_uint4(0, 0, 0, 0);

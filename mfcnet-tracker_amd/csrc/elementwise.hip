@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, lo
     }
     if (d.relu) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        for (int e = 0; e < E; ++e) acc[e] = relu_nan(acc[e]);
     }
     *(uint4*)((char*)d.out.ptr + ((((size_t)n * d.out.H + h) * d.out.W + w) * d.out.Cp + d.out.c_off + g * E) * sizeof(T)) = Gran<T>::pack(acc);
 }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, l
         }
         if (d.relu) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = fmaxf(acc[e], 0.f);
+            for (int e = 0; e < E; ++e) acc[e] = relu_nan(acc[e]);
         }
         *(uint4*)((char*)d.out.ptr + ((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(acc);
     }

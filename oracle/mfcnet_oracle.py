@@ -68,6 +68,7 @@ def hash_normal(key: str, n: int) -> np.ndarray:
     """n float32 ~N(0,1) values (Box-Muller on two hashed uniforms)."""
     u1 = hash_uniform(key + "#a", n).astype(np.float64)
     u2 = hash_uniform(key + "#b", n).astype(np.float64)
+    u1 = np.minimum(u1, 1.0 - 2.0 ** -24)          # (the float32 rounding of hash_uniform can return exactly 1.0: log(0))
     r = np.sqrt(-2.0 * np.log(1.0 - u1))
     return (r * np.cos(2.0 * math.pi * u2)).astype(np.float32)
 

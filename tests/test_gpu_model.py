@@ -299,3 +299,53 @@ def test_captured_graph_replays_the_forward_program(mfc):
     assert float((out - y_ref).abs().max()) <= 1e-5
     compare_logits(z, out.cpu().numpy(), ATOL)
     assert L.lib.mfc_graph_destroy(ex) == 0
+
+
+def test_max_size_720x960_t5_eval_vs_oracle(mfc):
+    """BASELINE config 5's shape: T=5, 720x960 (odd 23x30 level), RGB + depth + flow, HRNet-W48 -- eval-mode logits of the
+    HIP model (fp32) against the CPU oracle on the same hashed weights / inputs; and the reference's own limit: the Basic
+    warp cannot run above 576x720 (multiframe_model.py:156-167 raises there; here: an MfcError)."""
+    from oracle import mfcnet_oracle as O
+    T, H, W = 5, 720, 960
+    cfg = dict(name="max720", model_type="HRNetMulti-Large", T=T, optflow=True, depth=True, B=1, H=H, W=W, mode="eval")
+    frames, flows, depths, mask = case_inputs(cfg)
+    sd = case_state(cfg)
+    net = O.Net(sd, cfg["model_type"], 48, 5, T, True, True).eval()
+    with torch.no_grad():
+        ref = net(frames, optflow=flows, depth=depths)
+    m = build(mfc, cfg)
+    m.eval()
+    with torch.no_grad():
+        y = m(dev(frames), optflow=dev(flows), depth=dev(depths)).cpu()
+    assert tuple(y.shape) == (1, 5, H, W)
+    assert float((y - ref).abs().max()) <= ATOL
+    del m
+    torch.cuda.empty_cache()
+    cfgb = dict(cfg, model_type="HRNetMulti-Basic", depth=False)
+    mb = build(mfc, cfgb)
+    mb.eval()
+    with pytest.raises(Exception):
+        with torch.no_grad():
+            mb(dev(frames), optflow=dev(flows))
+
+
+def test_non_finite_inputs_propagate(mfc):
+    """torch.relu keeps NaN, so a diverged activation reaches the reference's logits and its `isnan(loss)` check
+    (src/engine.py:67).  The fused ReLUs here must not swallow it (v_max_f32 would): an inf in one flow element or one frame
+    pixel makes the oracle's and the HIP model's logits non-finite in the same places."""
+    from oracle import mfcnet_oracle as O
+    cfg, _ = load_case("large_all_train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    flows[1][0, 0, 31, 55] = float("inf")
+    frames[2][1, 1, 10, 20] = float("inf")
+    net = O.Net(case_state(cfg), cfg["model_type"], 48, 5, cfg["T"], True, True).eval()
+    with torch.no_grad():
+        ref = net(frames, optflow=flows, depth=depths)
+    m = build(mfc, cfg)
+    m.eval()
+    with torch.no_grad():
+        y = m(dev(frames), optflow=dev(flows), depth=dev(depths)).cpu()
+    bad_ref, bad = ~torch.isfinite(ref), ~torch.isfinite(y)
+    assert int(bad_ref.sum()) > 0 and bool((bad == bad_ref).all())
+    good = ~bad_ref
+    assert float((y[good] - ref[good]).abs().max()) <= ATOL if int(good.sum()) else True
