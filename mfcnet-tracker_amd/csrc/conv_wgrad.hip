@@ -20,6 +20,9 @@ int mfc_conv_set_force_mt(int v);
 int mfc_conv_set_grid(int v);
 int mfc_conv_set_ablate(int v);
 static int g_wgrad_ablate = 0;
+static int g_wgrad_deep = 0;          // prefetch-distance-2 wave kernel when a launch has at most one workgroup per CU.  Alone it is 15 % faster
+                                     // (35.7 -> 30.2 us), but its 308 VGPRs cannot share a SIMD with a conv wave (246), so next to the
+                                     // critical chain the step gets SLOWER (546 -> 530 frames/s): off by default; mfc_set_flag(17, v)
 static int g_wgrad_blocks = 256;     // target workgroups per wave-kernel launch (S = blocks / Y).  Alone, 512 (2 per CU) is fastest; in the
                                      // step the launches run on the detached stream next to the critical chain, and 1 per CU leaves that
                                      // chain half of every CU (measured 541 vs 529 frames/s); tuning: mfc_set_flag(11, n)
@@ -48,6 +51,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 14) return mfc_set_own_main(value);
     if (id == 15) return mfc_set_skip_kinds(value);
     if (id == 16) return mfc_set_async_prio(value);
+    if (id == 17) { g_wgrad_deep = value; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
@@ -514,8 +518,8 @@ struct WgradBatch {
     const float* coef[MFC_WGRAD_MAXBATCH]; int relu[MFC_WGRAD_MAXBATCH]; int n;
 };
 
-template <int TAA, int TB, int WCO, int WCI, int XP>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p, WgradBatch tb) {
+template <int TAA, int TB, int WCO, int WCI, int XP, int PF>
+__global__ __launch_bounds__(256, PF == 2 ? 1 : 2) void conv_wgrad_wave_kernel(WgradW p, WgradBatch tb) {
     typedef bf16_t T;
     constexpr int E = 8;
     constexpr int DP = 3;
@@ -591,8 +595,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p, Wgrad
 #pragma unroll
             for (int j = 0; j < WCI; ++j) acc[b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    uint4 dreg[DP], xreg[XP]; unsigned dmask = 0, xmask = 0;
-    int x_grp = 0; bool interior = false;
+    // one staged sub-tile in registers (global loads in flight or landed) with what the LDS store needs to know about it
+    struct Stage { uint4 d[DP]; uint4 x[XP]; unsigned dmask, xmask; int grp; bool interior; };
     const bool xf = (p.in_coef != nullptr);
     const float relu_floor = p.in_relu ? 0.f : -3.0e38f;
 
@@ -607,22 +611,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p, Wgrad
         return c;
     };
 
-    auto load_tile = [&](const TC& c) {
+    auto load_tile = [&](const TC& c, Stage& S) {
         const int n = c.n, i0 = c.tyi * p.TH, j0 = c.txi * p.TW;
-        x_grp = n / p.ipg;
+        S.grp = n / p.ipg;
         const int ihb = i0 * p.s + p.dh0 + a, iwb = j0 * p.s + p.dw0;
-        interior = i0 + p.TH <= p.Hout && j0 + p.TW <= p.Wout && ihb >= 0 && ihb + p.PHX <= p.Hin && iwb >= 0 && iwb + p.PW <= p.Win;
+        S.interior = i0 + p.TH <= p.Hout && j0 + p.TW <= p.Wout && ihb >= 0 && ihb + p.PHX <= p.Hin && iwb >= 0 && iwb + p.PW <= p.Win;
         const char* dimg = p.dy + ((size_t)n * p.Hout * p.Wout * p.Cout_p + co0) * sizeof(T);
         const char* ximg = p.x + ((size_t)n * p.Hin * p.Win * p.Cin_p + ci0) * sizeof(T);
-        if (interior) {
+        if (S.interior) {
             const char* dt = dimg + (size_t)(i0 * p.Wout + j0) * (p.Cout_p * (int)sizeof(T));
             const char* xt = ximg + (size_t)(ihb * p.Win + iwb) * (p.Cin_p * (int)sizeof(T));
 #pragma unroll
-            for (int i = 0; i < DP; ++i) dreg[i] = *(const uint4*)(dt + (unsigned)d_vof[i]);
+            for (int i = 0; i < DP; ++i) S.d[i] = *(const uint4*)(dt + (unsigned)d_vof[i]);
 #pragma unroll
-            for (int i = 0; i < XP; ++i) xreg[i] = *(const uint4*)(xt + (unsigned)x_vof[i]);
+            for (int i = 0; i < XP; ++i) S.x[i] = *(const uint4*)(xt + (unsigned)x_vof[i]);
         } else {
-            dmask = 0; xmask = 0;
+            S.dmask = 0; S.xmask = 0;
             const int drow = p.Cout_p * (int)sizeof(T), xrow = p.Cin_p * (int)sizeof(T);
 #pragma unroll
             for (int i = 0; i < DP; ++i) {
@@ -630,8 +634,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p, Wgrad
                 const bool inr = ((dstat >> i) & 1u) && oi < p.Hout && oj < p.Wout;
                 const int oic = min(oi, p.Hout - 1), ojc = min(oj, p.Wout - 1);
                 const int gic = ((dstat >> i) & 1u) ? (dpk[i] & 15) : 0;
-                dreg[i] = *(const uint4*)(dimg + (unsigned)((oic * p.Wout + ojc) * drow + gic * 16));
-                dmask |= (inr ? 1u : 0u) << i;
+                S.d[i] = *(const uint4*)(dimg + (unsigned)((oic * p.Wout + ojc) * drow + gic * 16));
+                S.dmask |= (inr ? 1u : 0u) << i;
             }
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
@@ -639,31 +643,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p, Wgrad
                 const bool inr = ((xstat >> i) & 1u) && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
                 const int ihc = min(max(ih, 0), p.Hin - 1), iwc = min(max(iw, 0), p.Win - 1);
                 const int gic = ((xstat >> i) & 1u) ? (xpk[i] & 15) : 0;
-                xreg[i] = *(const uint4*)(ximg + (unsigned)((ihc * p.Win + iwc) * xrow + gic * 16));
-                xmask |= (inr ? 1u : 0u) << i;
+                S.x[i] = *(const uint4*)(ximg + (unsigned)((ihc * p.Win + iwc) * xrow + gic * 16));
+                S.xmask |= (inr ? 1u : 0u) << i;
             }
         }
     };
     // every lane stores every piece (no divergence): dead pieces go to the dummy slot
-    auto store_tile = [&](char* buf) {
+    auto store_tile = [&](char* buf, const Stage& S) {
 #pragma unroll
         for (int i = 0; i < DP; ++i) {
-            uint4 v = dreg[i];
-            if (!interior && !(dmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
+            uint4 v = S.d[i];
+            if (!S.interior && !(S.dmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
             *(uint4*)(buf + d_lds[i]) = v;
         }
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            uint4 v = xreg[i];
+            uint4 v = S.x[i];
             if (xf) {
-                const float* cf = coefs + (size_t)x_grp * 2 * (p.gx * 8) + (xpk[i] & 15) * E;
+                const float* cf = coefs + (size_t)S.grp * 2 * (p.gx * 8) + (xpk[i] & 15) * E;
                 float f[E];
                 Gran<T>::unpack(v, f);
 #pragma unroll
                 for (int e = 0; e < E; ++e) f[e] = relu_nan(f[e] * cf[e] + cf[p.gx * 8 + e], relu_floor);
                 v = Gran<T>::pack(f);
             }
-            if (!interior && !(xmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
+            if (!S.interior && !(S.xmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
             *(uint4*)(buf + x_lds[i]) = v;
         }
     };
@@ -674,19 +678,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p, Wgrad
     int tile = bsplit * 4 + wave;
     TC tc;
     { tc.txi = tile % p.tilesX; const int r = tile / p.tilesX; tc.tyi = r % p.tilesY; tc.n = r / p.tilesY; }
-    if (tile < p.ntiles) { load_tile(tc); store_tile(wbase); }
     const int pr0 = 8 * (lane >> 4) + ((lane & 15) >> 2);
     const int csub = (lane & 3) * 8;
     const int xo0 = xoff[pr0] + csub, xo1 = xoff[pr0 + 4] + csub;
-    for (int it = 0; tile < p.ntiles; tile += stride, ++it) {
-        const int nxt = tile + stride;
-        tc = tc_next(tc);
-        if (nxt < p.ntiles && !(p.ablate & 1)) load_tile(tc);
-        const char* Ds = wbase + (it & 1) * p.buf_bytes;
+    auto compute = [&](int par) {                  // all MFMAs of the sub-tile staged in LDS buffer `par`
+        const char* Ds = wbase + par * p.buf_bytes;
         const char* Xs = Ds + p.off_x;
         const char* dA0 = Ds + pr0 * p.pitch_d + csub;
         const char* dA1 = dA0 + 4 * p.pitch_d;
-        if (p.ablate & 4) { if (nxt < p.ntiles && !(p.ablate & 2)) store_tile(wbase + ((it + 1) & 1) * p.buf_bytes); continue; }
+        if (p.ablate & 4) return;
         bf16x8 af[WCO];
 #pragma unroll
         for (int i = 0; i < WCO; ++i) {
@@ -710,7 +710,48 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wave_kernel(WgradW p, Wgrad
                 for (int j = 0; j < WCI; ++j)
                     acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[b][i][j], 0, 0, 0);
         }
-        if (nxt < p.ntiles && !(p.ablate & 2)) store_tile(wbase + ((it + 1) & 1) * p.buf_bytes);
+    };
+    if constexpr (PF == 1) {
+        Stage S;
+        if (tile < p.ntiles) { load_tile(tc, S); store_tile(wbase, S); }
+        for (int it = 0; tile < p.ntiles; tile += stride, ++it) {
+            const int nxt = tile + stride;
+            tc = tc_next(tc);
+            if (nxt < p.ntiles && !(p.ablate & 1)) load_tile(tc, S);
+            compute(it & 1);
+            if (nxt < p.ntiles && !(p.ablate & 2)) store_tile(wbase + ((it + 1) & 1) * p.buf_bytes, S);
+        }
+    } else {
+        // Prefetch distance 2 (one workgroup per CU: a wave has a SIMD to itself, so nobody else hides its load latency; the
+        // 512-register budget of that occupancy pays for a second set of staging registers).  While sub-tile t is multiplied
+        // out of LDS buffer t&1, the loads of t+1 (issued an iteration ago) land and are stored into the other buffer, and the
+        // loads of t+2 are already in flight.
+        Stage SA, SB;
+        if (tile < p.ntiles) {
+            load_tile(tc, SA); store_tile(wbase, SA);
+            tc = tc_next(tc);
+            if (tile + stride < p.ntiles) load_tile(tc, SB);
+        }
+        for (;;) {
+            if (tile >= p.ntiles) break;
+            {   // even step: compute buffer 0, t+2 -> SA, land / store t+1 from SB into buffer 1
+                const bool has1 = tile + stride < p.ntiles, has2 = tile + 2 * stride < p.ntiles;
+                tc = tc_next(tc);
+                if (has2 && !(p.ablate & 1)) load_tile(tc, SA);
+                compute(0);
+                if (has1 && !(p.ablate & 2)) store_tile(wbase + p.buf_bytes, SB);
+                tile += stride;
+            }
+            if (tile >= p.ntiles) break;
+            {   // odd step: compute buffer 1, t+2 -> SB, store t+1 from SA into buffer 0
+                const bool has1 = tile + stride < p.ntiles, has2 = tile + 2 * stride < p.ntiles;
+                tc = tc_next(tc);
+                if (has2 && !(p.ablate & 1)) load_tile(tc, SB);
+                compute(1);
+                if (has1 && !(p.ablate & 2)) store_tile(wbase, SA);
+                tile += stride;
+            }
+        }
     }
     if (p.ablate & 8) return;
     // ---- tree-reduce the four waves' accumulators through LDS, then one wave issues the atomics ----
@@ -872,11 +913,11 @@ static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) 
     return MFC_ERR_UNSUPPORTED;
 }
 
-template <int TAA, int TB, int WCO, int WCI, int XP>
+template <int TAA, int TB, int WCO, int WCI, int XP, int PF>
 static int wgrad_wave_launch(const WgradW& f, const WgradBatch& tb, size_t lds, int Y, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on) {
@@ -884,7 +925,7 @@ static int wgrad_wave_launch(const WgradW& f, const WgradBatch& tb, size_t lds, 
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0 * tb.n;
         mfc_prof_before(st, 1 * 64 + 32 + 16 + (TB == 3 ? 0 : 1), flops, bytes);
     }
-    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP>), dim3(f.splits * Y * tb.n), dim3(256), lds, st, f, tb);
+    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP, PF>), dim3(f.splits * Y * tb.n), dim3(256), lds, st, f, tb);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -979,8 +1020,12 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only, 
         const mfc_wgrad_desc* q = (batch && i < nb) ? &batch[i] : d;
         wb.x[i] = (const char*)q->x; wb.dy[i] = (const char*)q->dy; wb.dwp[i] = q->dwp; wb.coef[i] = q->in_coef; wb.relu[i] = q->in_relu;
     }
-    if (alltaps) return wgrad_wave_launch<3, 3, 2, 2, 4>(f, wb, lds, Y, st);
-#define WGW(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) return nxp <= 4 ? wgrad_wave_launch<1, tb, a_, b_, 4>(f, wb, lds, Y, st) : wgrad_wave_launch<1, tb, a_, b_, 7>(f, wb, lds, Y, st);
+    // one workgroup per CU (grid <= 256): the prefetch-distance-2 variant (1 wave per SIMD, 512 registers)
+    const bool deep = g_wgrad_deep && (long)f.splits * Y * nb <= 256;
+    if (alltaps) return deep ? wgrad_wave_launch<3, 3, 2, 2, 4, 2>(f, wb, lds, Y, st) : wgrad_wave_launch<3, 3, 2, 2, 4, 1>(f, wb, lds, Y, st);
+#define WGW(tb, a_, b_) if (d->TB == tb && WCO == a_ && WCI == b_) { \
+        if (nxp <= 4) return deep ? wgrad_wave_launch<1, tb, a_, b_, 4, 2>(f, wb, lds, Y, st) : wgrad_wave_launch<1, tb, a_, b_, 4, 1>(f, wb, lds, Y, st); \
+        return deep ? wgrad_wave_launch<1, tb, a_, b_, 7, 2>(f, wb, lds, Y, st) : wgrad_wave_launch<1, tb, a_, b_, 7, 1>(f, wb, lds, Y, st); }
     WGW(3, 3, 3) WGW(3, 3, 2) WGW(3, 3, 1) WGW(3, 2, 3) WGW(3, 2, 2) WGW(3, 2, 1) WGW(3, 1, 3) WGW(3, 1, 2) WGW(3, 1, 1)
     WGW(11, 1, 2) WGW(11, 1, 1)
 #undef WGW
