@@ -393,8 +393,15 @@ typedef struct { double ms[MFC_PROF_BUCKETS]; double flops[MFC_PROF_BUCKETS]; do
 int mfc_prof_enable(int on);
 int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded events, fills `out`, clears the log */
 
-/* tuning switches: id 1 = use ds_read_b64_tr_b16 in the bf16 wgrad kernel (default 1); id 9 = honour record lanes
- * (bit 0: parallel-section lanes, bit 1: detached records; default 3; 0 runs every record on the caller's stream); others are kernel-tuning knobs (see the sources) */
+/* Tuning switches (defaults are the measured optima; the tools/ scripts sweep them).  Process-global, not thread-safe.
+ *   1  wgrad: use ds_read_b64_tr_b16 (1)            2  conv: force pixel-tile MT (0 = search)     3  wgrad: K-split mode (0)
+ *   4  conv: persistent workgroups per launch (512)  5  conv: ablation mask (0)                    6  conv: LDS budget KiB (80)
+ *   7  wgrad: ablation mask (0)                      8  conv: cout-block-fastest unit order (-1 auto)
+ *   9  lanes: bit 0 parallel-section lanes, bit 1 detached records (3); 0 = every record on the caller's stream
+ *  10  detached streams in use (1)                  11  wgrad: target workgroups per launch (256; sizes the partial-sum slices)
+ *  12  lane -> stream folding (n streams, or a 4-digit map such as 1221)   13  run detached records on side lane k (0 = own stream)
+ *  14  program main stream = interpreter's own (0)  15  what-if: skip record kinds (bit mask, timing only)
+ *  16  detached stream priority (0; read at stream creation)              17  wgrad: prefetch-distance-2 variant (0) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);
