@@ -36,6 +36,7 @@ struct ConvK {
     int Yblocks, nunits, per_block;     // units = cout blocks (slow) x tiles (fast); units per workgroup
     int nslots, npieces, stage_bytes;   // weight slots per stage, 1-KiB DMA pieces per stage, bytes of one stage image
     int off_w0, off_w1, off_ktab, off_red;   // LDS offsets (bytes)
+    int off_dummy;                           // 16-byte LDS slot dead staging pieces are stored to
     int ybfast;                              // unit order: 1 = cout block fastest (the Yblocks units of a pixel tile run back to back on one workgroup: the re-reads of the tile hit L2 instead of HBM)
     int ablate;                              // tuning only: 1 skip weight DMA, 2 skip patch staging, 4 skip output stores, 8 skip MFMAs
 };
@@ -87,11 +88,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     int KGP = 1; while (KGP < kg) KGP <<= 1;
     const int p_gi = tid & (KGP - 1), pstep = 256 / KGP;
     int pyx[PMAX];
+    // FA ("fast addressing", variants with register slack): per piece the byte offset from the first patch pixel of an interior
+    // tile (pgo) and the LDS byte offset (plo, a dummy slot for pieces that carry nothing), so that the prefetch of an interior
+    // tile is `scalar base + constant lane offset` (no vector arithmetic) and the LDS store is branch-free
+    constexpr bool FA = (NT * MT <= 8) || (MT == 2 && NT <= 4 && PMAX <= 4);
+    int pgo[FA ? PMAX : 1], plo[FA ? PMAX : 1];
+    unsigned pvalid = 0;
 #pragma unroll
     for (int i = 0; i < PMAX; ++i) {
         const int pix = tid / KGP + i * pstep;
         const int py = pix / p.PW, px = pix - py * p.PW;
-        pyx[i] = (pix < npix && p_gi < kg) ? ((py << 16) | px) : -1;
+        const bool ok = pix < npix && p_gi < kg;
+        pyx[i] = ok ? ((py << 16) | px) : -1;
+        pvalid |= (ok ? 1u : 0u) << i;
+        if constexpr (FA) {
+            pgo[i] = ok ? ((py * p.Win + px) * p.Cin_p * (int)sizeof(T) + p_gi * 16) : 0;
+            plo[i] = ok ? ((py * p.PW + px) * p.pitch + p_gi * 16) : p.off_dummy;
+        }
     }
     // slot -> patch offset table (tail slots repeat the last valid one; their packed weights are zero)
     if (tid < p.nslots) {
@@ -151,12 +164,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         const int cs = p.Cin_p * (int)sizeof(T);
         if (ih0 >= 0 && iw0 >= 0 && ih0 + p.PH <= p.Hin && iw0 + p.PW <= p.Win) {
             // interior tile (uniform branch): no bounds arithmetic at all
-            const char* tb = base + (size_t)(ih0 * p.Win + iw0) * cs;
+            if constexpr (FA) {
+                const char* tb = p.in + ((size_t)n * p.Hin * p.Win + (size_t)(ih0 * p.Win + iw0)) * cs + (size_t)g0 * 16;      // wave-uniform
 #pragma unroll
-            for (int i = 0; i < PMAX; ++i) {
-                const int pv = pyx[i] >= 0 ? pyx[i] : 0;
-                preg[i] = *(const uint4*)(tb + ((pv >> 16) * p.Win + (pv & 0xffff)) * cs);
-                pmask |= (pyx[i] >= 0 ? 1u : 0u) << i;
+                for (int i = 0; i < PMAX; ++i) preg[i] = *(const uint4*)(tb + (unsigned)pgo[i]);
+                pmask = pvalid;
+            } else {
+                const char* tb = base + (size_t)(ih0 * p.Win + iw0) * cs;
+#pragma unroll
+                for (int i = 0; i < PMAX; ++i) {
+                    const int pv = pyx[i] >= 0 ? pyx[i] : 0;
+                    preg[i] = *(const uint4*)(tb + ((pv >> 16) * p.Win + (pv & 0xffff)) * cs);
+                    pmask |= (pyx[i] >= 0 ? 1u : 0u) << i;
+                }
             }
         } else {
 #pragma unroll
@@ -170,6 +190,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         }
     };
     auto store_patch = [&]() {
+        if constexpr (FA) {
+            // every lane stores every piece: dead pieces land in the dummy slot, out-of-image pieces store zeros
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) {
+                uint4 v = preg[i];
+                if (p_xf) {
+                    float f[E];
+                    Gran<T>::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        float t = f[e] * sc[e] + sh[e];
+                        f[e] = p.in_relu ? relu_nan(t) : t;
+                    }
+                    v = Gran<T>::pack(f);
+                }
+                if (!(pmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
+                *(uint4*)(smem + plo[i]) = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
             if (pyx[i] >= 0) {
@@ -479,7 +519,8 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
                 t.off_w1 = t.off_w0 + (int)wbytes;
                 t.off_ktab = t.off_w1 + (int)wbytes;
                 t.off_red = t.off_ktab + ((t.nslots * 4 + 15) & ~15);
-                const size_t l = (size_t)t.off_red + (size_t)2 * 4 * 2 * NT * 16 * 4;
+                t.off_dummy = t.off_red + 2 * 4 * 2 * NT * 16 * 4;
+                const size_t l = (size_t)t.off_dummy + 16;
                 const int pm = ceil_div(t.PH * t.PW, 256 / KGP);
                 // register budget (no spills: a spill in the prefetch path serialises it): wide N tiles keep fewer
                 // pixel tiles / prefetch pieces per thread
