@@ -15,6 +15,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <typename T> struct Gran;
 template <> struct Gran<float> {
     static constexpr int E = 4;
+    typedef float4 Quad;                                       // 4 consecutive channels
+    __device__ static inline void unquad(const float4& v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+    __device__ static inline float4 quad(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
     __device__ static inline void unpack(const uint4& v, float* f) {
         f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
         f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
@@ -38,6 +41,12 @@ __device__ inline unsigned pack_bf16x2(float lo, float hi) {      // one v_cvt_p
 }
 template <> struct Gran<bf16_t> {
     static constexpr int E = 8;
+    typedef uint2 Quad;                                        // 4 consecutive channels
+    __device__ static inline void unquad(const uint2& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+    __device__ static inline uint2 quad(const float* f) { return make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3])); }
     __device__ static inline void unpack(const uint4& v, float* f) {
         f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
         f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     constexpr int E = Gran<T>::E;
     constexpr bool BF = (E == 8);
     constexpr int NT16 = NT * 16;
+    constexpr bool FA = (NT * MT <= 8) || (MT == 2 && NT <= 4 && PMAX <= 4);      // variants with register slack (see below)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     int* ktab = (int*)(smem + p.off_ktab);
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 
     // ---------------- one-time per-thread tables (tile shape is fixed for the whole launch) ----------------
     int pbase[MT]; int pty[MT], ptx[MT]; bool pin[MT];
+    int eoff[FA ? MT : 1];                   // byte offset of the lane's output cell from the tile origin (used by the FA epilogue)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int pp = (wave * MT + mt) * 16 + (lane & 15);
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         if (!v) { ty = 0; tx = 0; }
         pty[mt] = ty; ptx[mt] = tx; pin[mt] = v;
         pbase[mt] = ((ty * p.s) * p.PW + tx * p.s) * p.pitch + (BF ? 0 : (lane >> 4) * 4);
+        if constexpr (FA) eoff[mt] = (((ty * p.osh) * p.Wout + tx * p.osw) * p.Cout_p + (lane >> 4) * 4) * (int)sizeof(T);
     }
     // patch pieces this thread stages: granule p_gi of pixels tid/KGP + i*pstep  (py<<16|px, or -1)
     int KGP = 1; while (KGP < kg) KGP <<= 1;
@@ -91,7 +94,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     // FA ("fast addressing", variants with register slack): per piece the byte offset from the first patch pixel of an interior
     // tile (pgo) and the LDS byte offset (plo, a dummy slot for pieces that carry nothing), so that the prefetch of an interior
     // tile is `scalar base + constant lane offset` (no vector arithmetic) and the LDS store is branch-free
-    constexpr bool FA = (NT * MT <= 8) || (MT == 2 && NT <= 4 && PMAX <= 4);
     int pgo[FA ? PMAX : 1], plo[FA ? PMAX : 1];
     unsigned pvalid = 0;
 #pragma unroll
@@ -361,6 +363,56 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         if (c == p.nchunks - 1 && a == p.nstg - 1 && !(p.ablate & 64)) {
             const int n = uc.n, i0 = uc.tyi * p.TH, j0 = uc.txi * p.TW, yb = uc.yb;
             const int n0 = yb * NT16;
+            if constexpr (FA) {
+                // Variants with register slack: wave-uniform tile origin + the per-lane offsets of the prologue (no 64-bit
+                // vector address math per store), the read-modify-write loads of a pixel row issued together before their use
+                char* tbase = p.out + ((((size_t)n * p.Hout + (i0 * p.osh + p.ooh)) * p.Wout + (j0 * p.osw + p.oow)) * p.Cout_p + n0) * sizeof(T);
+                const bool full = (i0 + p.TH <= p.Hl) && (j0 + p.TW <= p.Wl);
+                bool vco[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) vco[nt] = (n0 + nt * 16 + cq) < p.Cout_p;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bool vpx = pin[mt] && (full || ((i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl)));
+                    typename Gran<T>::Quad oldv[NT];
+                    if (p.accumulate) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const unsigned off = (vpx && vco[nt]) ? (unsigned)(eoff[mt] + nt * 16 * (int)sizeof(T)) : 0u;
+                            oldv[nt] = *(const typename Gran<T>::Quad*)(tbase + off);
+                        }
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = acc[mt][nt][r];
+                            acc[mt][nt][r] = 0.f;
+                        }
+                        if (p.bias) {          // (only the last_layer and head convolutions carry a bias)
+                            float bq[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) bq[r] = p.bias[min(n0 + nt * 16 + cq + r, p.Cout - 1)];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (n0 + nt * 16 + cq + r) < p.Cout ? bq[r] : 0.f;
+                        }
+                        if (p.accumulate) {
+                            float o4[4];
+                            Gran<T>::unquad(oldv[nt], o4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += o4[r];
+                        }
+                        if (vpx && vco[nt] && !(p.ablate & 4)) {
+                            *(typename Gran<T>::Quad*)(tbase + (unsigned)(eoff[mt] + nt * 16 * (int)sizeof(T))) = Gran<T>::quad(v);
+                            if (p.out_stats) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { ssum[nt][r] += v[r]; ssq[nt][r] += v[r] * v[r]; }
+                            }
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool valid = pin[mt] && (i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl);
@@ -402,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                         }
                     }
                 }
+            }
             }
             if (p.out_stats) {
                 // flush the running sums when the next unit belongs to another (statistic group, cout block) or the run ends
