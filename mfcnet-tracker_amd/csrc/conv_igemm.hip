@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 
     // ---------------- one-time per-thread tables (tile shape is fixed for the whole launch) ----------------
     int pbase[MT]; int pty[MT], ptx[MT]; bool pin[MT];
+    int eoff16[FA ? MT : 1];
     int eoff[FA ? MT : 1];                   // byte offset of the lane's output cell from the tile origin (used by the FA epilogue)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -85,7 +86,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         if (!v) { ty = 0; tx = 0; }
         pty[mt] = ty; ptx[mt] = tx; pin[mt] = v;
         pbase[mt] = ((ty * p.s) * p.PW + tx * p.s) * p.pitch + (BF ? 0 : (lane >> 4) * 4);
-        if constexpr (FA) eoff[mt] = (((ty * p.osh) * p.Wout + tx * p.osw) * p.Cout_p + (lane >> 4) * 4) * (int)sizeof(T);
+        if constexpr (FA) {
+            eoff[mt] = (((ty * p.osh) * p.Wout + tx * p.osw) * p.Cout_p + (lane >> 4) * 4) * (int)sizeof(T);
+            eoff16[mt] = (((ty * p.osh) * p.Wout + tx * p.osw) * p.Cout_p + (lane >> 4) * 8) * (int)sizeof(T);      // transposed pair layout: 8 channels per lane
+        }
     }
     // patch pieces this thread stages: granule p_gi of pixels tid/KGP + i*pstep  (py<<16|px, or -1)
     int KGP = 1; while (KGP < kg) KGP <<= 1;
@@ -365,29 +369,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
             const int n0 = yb * NT16;
             if constexpr (FA) {
                 // Variants with register slack: wave-uniform tile origin + the per-lane offsets of the prologue (no 64-bit
-                // vector address math per store), the read-modify-write loads of a pixel row issued together before their use
+                // vector address math per store).  bf16: the MFMA leaves a lane with 4 channels of cout tile nt; two cout tiles
+                // are transposed across the four 16-lane rows (v_permlane32_swap + v_permlane16_swap) so that every lane owns
+                // 8 CONTIGUOUS channels of its pixel -> one 16-byte store per tile pair, 64 contiguous bytes per pixel (the
+                // 8-byte stores to 32-byte half lines cost ~250 cycles of issue each: the memory pipeline works per line touched)
                 char* tbase = p.out + ((((size_t)n * p.Hout + (i0 * p.osh + p.ooh)) * p.Wout + (j0 * p.osw + p.oow)) * p.Cout_p + n0) * sizeof(T);
                 const bool full = (i0 + p.TH <= p.Hl) && (j0 + p.TW <= p.Wl);
-                bool vco[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) vco[nt] = (n0 + nt * 16 + cq) < p.Cout_p;
+                constexpr int NP = BF ? NT / 2 : 0;              // cout tile pairs stored transposed
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const bool vpx = pin[mt] && (full || ((i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl)));
-                    typename Gran<T>::Quad oldv[NT];
-                    if (p.accumulate) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const unsigned off = (vpx && vco[nt]) ? (unsigned)(eoff[mt] + nt * 16 * (int)sizeof(T)) : 0u;
-                            oldv[nt] = *(const typename Gran<T>::Quad*)(tbase + off);
-                        }
-                    }
+                    float v[NT][4];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            v[r] = acc[mt][nt][r];
+                            v[nt][r] = acc[mt][nt][r];
                             acc[mt][nt][r] = 0.f;
                         }
                         if (p.bias) {          // (only the last_layer and head convolutions carry a bias)
@@ -395,19 +392,73 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) bq[r] = p.bias[min(n0 + nt * 16 + cq + r, p.Cout - 1)];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (n0 + nt * 16 + cq + r) < p.Cout ? bq[r] : 0.f;
+                            for (int r = 0; r < 4; ++r) v[nt][r] += (n0 + nt * 16 + cq + r) < p.Cout ? bq[r] : 0.f;
                         }
+                    }
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int pr = 0; pr < NP; ++pr) {
+                            // lane (row g = lane>>4) after the transpose: channels pr*32 + 8g .. +7 of its pixel
+                            const unsigned off = (unsigned)(eoff16[mt] + pr * 64);
+                            const bool vc = (n0 + pr * 32 + (lane >> 4) * 8) < p.Cout_p;
+                            uint4 oldq = make_uint4(0, 0, 0, 0);
+                            if (p.accumulate) oldq = *(const uint4*)(tbase + ((vpx && vc) ? off : 0u));
+                            if (p.accumulate) {
+                                // dgrad accumulation happens in fp32 on the transposed layout: expand, transpose, add, round once
+                                float w[8];
+                                // (the sums must be rounded once: transpose the fp32 values as raw dwords)
+                                unsigned t0[4], t1[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    auto x32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * pr][r]), __float_as_uint(v[2 * pr + 1][r]), false, false);
+                                    auto x16 = __builtin_amdgcn_permlane16_swap(x32[0], x32[1], false, false);
+                                    t0[r] = x16[0]; t1[r] = x16[1];
+                                }
+                                float o8[8];
+                                Gran<T>::unpack(oldq, o8);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { w[r] = __uint_as_float(t0[r]) + o8[r]; w[4 + r] = __uint_as_float(t1[r]) + o8[4 + r]; }
+                                if (p.out_stats) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        if (vpx && (n0 + 2 * pr * 16 + cq) < p.Cout_p) { ssum[2 * pr][r] += v[2 * pr][r]; ssq[2 * pr][r] += v[2 * pr][r] * v[2 * pr][r]; }
+                                        if (vpx && (n0 + (2 * pr + 1) * 16 + cq) < p.Cout_p) { ssum[2 * pr + 1][r] += v[2 * pr + 1][r]; ssq[2 * pr + 1][r] += v[2 * pr + 1][r] * v[2 * pr + 1][r]; }
+                                    }
+                                }
+                                if (vpx && vc && !(p.ablate & 4)) *(uint4*)(tbase + off) = Gran<T>::pack(w);
+                            } else {
+                                const unsigned p0 = pack_bf16x2(v[2 * pr][0], v[2 * pr][1]), p1 = pack_bf16x2(v[2 * pr][2], v[2 * pr][3]);
+                                const unsigned q0 = pack_bf16x2(v[2 * pr + 1][0], v[2 * pr + 1][1]), q1 = pack_bf16x2(v[2 * pr + 1][2], v[2 * pr + 1][3]);
+                                auto a32 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                                auto a16 = __builtin_amdgcn_permlane16_swap(a32[0], a32[1], false, false);
+                                auto b32 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                                auto b16 = __builtin_amdgcn_permlane16_swap(b32[0], b32[1], false, false);
+                                if (p.out_stats) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        if (vpx && (n0 + 2 * pr * 16 + cq) < p.Cout_p) { ssum[2 * pr][r] += v[2 * pr][r]; ssq[2 * pr][r] += v[2 * pr][r] * v[2 * pr][r]; }
+                                        if (vpx && (n0 + (2 * pr + 1) * 16 + cq) < p.Cout_p) { ssum[2 * pr + 1][r] += v[2 * pr + 1][r]; ssq[2 * pr + 1][r] += v[2 * pr + 1][r] * v[2 * pr + 1][r]; }
+                                    }
+                                }
+                                if (vpx && vc && !(p.ablate & 4)) *(uint4*)(tbase + off) = make_uint4(a16[0], b16[0], a16[1], b16[1]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int nt = 2 * NP; nt < NT; ++nt) {      // tiles without a partner (odd NT, fp32): 4 channels per lane
+                        const bool vc = (n0 + nt * 16 + cq) < p.Cout_p;
+                        const unsigned off = (unsigned)(eoff[mt] + nt * 16 * (int)sizeof(T));
                         if (p.accumulate) {
                             float o4[4];
-                            Gran<T>::unquad(oldv[nt], o4);
+                            Gran<T>::unquad(*(const typename Gran<T>::Quad*)(tbase + ((vpx && vc) ? off : 0u)), o4);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += o4[r];
+                            for (int r = 0; r < 4; ++r) v[nt][r] += o4[r];
                         }
-                        if (vpx && vco[nt] && !(p.ablate & 4)) {
-                            *(typename Gran<T>::Quad*)(tbase + (unsigned)(eoff[mt] + nt * 16 * (int)sizeof(T))) = Gran<T>::quad(v);
+                        if (vpx && vc && !(p.ablate & 4)) {
+                            *(typename Gran<T>::Quad*)(tbase + off) = Gran<T>::quad(v[nt]);
                             if (p.out_stats) {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) { ssum[nt][r] += v[r]; ssq[nt][r] += v[r] * v[r]; }
+                                for (int r = 0; r < 4; ++r) { ssum[nt][r] += v[nt][r]; ssq[nt][r] += v[nt][r] * v[nt][r]; }
                             }
                         }
                     }

@@ -14,6 +14,8 @@ s = s.replace("        // ---------------- tile epilogue ----------------", "   
 s = s.replace("        // ---------------- hand over to the next stage ----------------\n        if (newpatch) {\n            __syncthreads();           // every wave has finished reading the current patch\n            if (!(p.ablate & 2)) store_patch();\n        }\n        dma_wait();                    // the weight DMA of stage g+1 has landed (this wave's pieces) ...\n        __syncthreads();               // ... and everybody's",
               "        TRACE(4);\n        if (newpatch) {\n            __syncthreads();\n            TRACE(5);\n            if (!(p.ablate & 2)) store_patch();\n            TRACE(6);\n        }\n        dma_wait();\n        TRACE(7);\n        __syncthreads();\n        TRACE(8);")
 s = s.replace("    if (red_pending) stats_flush();\n}\n\n// ------------------------------------------------------------------------------------------\nstatic void choose_tile", "    if (red_pending) stats_flush();\n    TRACE(9);\n    if (blockIdx.x == 7 && threadIdx.x == 0) g_trace[4095] = tr_n;\n}\n\nextern \"C\" int mfc_conv_trace_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(long long) * 4096) == hipSuccess ? 0 : -1; }\n\n// ------------------------------------------------------------------------------------------\nstatic void choose_tile")
+s = s.replace("                const bool full = (i0 + p.TH <= p.Hl) && (j0 + p.TW <= p.Wl);", "                TRACE(13);\n                const bool full = (i0 + p.TH <= p.Hl) && (j0 + p.TW <= p.Wl);")
+s = s.replace("                    const bool vpx = pin[mt] && (full ||", "                    TRACE(14);\n                    const bool vpx = pin[mt] && (full ||")
 assert s.count("TRACE(") >= 13, s.count("TRACE(")
 open(p, "w").write(s)
 print("instrumented", p)
