@@ -208,6 +208,9 @@ class HRNetMultiHIP(nn.Module):
     def _run_backward(self, plan, gout):
         params = [p for p in self.parameters()]
         live = params[0].grad is not None
+        if live and getattr(self, "grad_bucket_hook", None) is not None:
+            raise L.MfcError("gradient accumulation across backward passes cannot be combined with a gradient-bucket hook "
+                             "(the buckets are reduced while the pass runs): call zero_grad() before every backward")
         old = self._G.clone() if live else None
         plan.run_backward(gout)
         if old is not None:
