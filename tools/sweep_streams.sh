@@ -1,4 +1,6 @@
-for map in 1212 1222 1221 1122 1232 1233 1223 1231 1123; do
-  r=$(MFC_OWN_MAIN=0 MFC_LANE_STREAMS=$map timeout -k 10 300 python bench.py --no-cpu-baseline --no-prof --steps 10 2>&1 | tail -1 | sed 's/.*"value": \([0-9.]*\).*/\1/')
-  echo "map=$map -> $r"
-done
+# sweep the lane -> stream map / detached stream / wgrad workgroups on the full step (usage: bash tools/sweep_streams.sh [width])
+W=${1:-32}
+for map in 1221 1212 1222 1231; do for blk in 256 512; do
+  r=$(MFC_LANE_STREAMS=$map MFC_WGRAD_BLOCKS=$blk timeout -k 10 300 python bench.py --width $W --no-cpu-baseline --no-prof --steps 10 2>&1 | tail -1 | sed 's/.*"value": \([0-9.]*\).*/\1/')
+  echo "width=$W map=$map wgrad_blocks=$blk -> $r"
+done; done
