@@ -140,6 +140,8 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_CONV_FILL_PCT"):         # before the plan is built (the packed weight layouts depend on the geometry)
+        L.lib.mfc_set_flag(18, int(os.environ["MFC_CONV_FILL_PCT"]))
     if os.environ.get("MFC_CONV_GRID"):             # before the plan is built (sizes nothing, but the layouts are queried then)
         L.lib.mfc_set_flag(4, int(os.environ["MFC_CONV_GRID"]))
     if os.environ.get("MFC_ASYNC_PRIO"):            # before the first program run (read when the streams are created)

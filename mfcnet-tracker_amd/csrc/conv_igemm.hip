@@ -18,6 +18,7 @@
 // Replaces: nn.Conv2d forward / cuDNN dgrad of models/hrnet.py:39-42,82-88,200-230,361-386,334-351
 // and models/multiframe_model.py:191-201 (see include/mfcnet_hip.h).
 #include "common.h"
+#include <math.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
@@ -552,6 +553,8 @@ static int g_conv_lds_kb = 80;       // LDS budget per workgroup (80 KiB -> 2 wo
 int mfc_conv_set_lds_kb(int v) { g_conv_lds_kb = v > 0 ? v : 80; return 0; }
 static int g_conv_ybfast = -1;        // -1 auto, 0 never, 1 always; tuning: mfc_set_flag(8, v)
 int mfc_conv_set_ybfast(int v) { g_conv_ybfast = v; return 0; }
+static int g_conv_fill_pct = 100;     // exponent (in %) on the under-fill penalty of the geometry search; tuning: mfc_set_flag(18, pct)
+int mfc_conv_set_fill_pct(int v) { g_conv_fill_pct = v; return 0; }
 static int g_conv_ablate = 0;
 int mfc_conv_set_ablate(int v) { g_conv_ablate = v; return 0; }
 static int g_conv_grid = 512;        // persistent workgroups per launch (2 per CU); tuning: mfc_set_flag(4, n)
@@ -602,7 +605,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
         c.PH = (c.TH - 1) * c.s + c.TA; c.PW = (c.TW - 1) * c.s + c.TB;
         const long units = (long)c.N * c.tilesY * c.tilesX * c.Yblocks;
         // parallelism: a launch wants >= ~2 units per CU-slot (512 slots); fewer units -> idle CUs
-        const double fill = units >= 512 ? 1.0 : (double)units / 512.0;
+        const double fill = units >= 512 ? 1.0 : pow((double)units / 512.0, g_conv_fill_pct / 100.0);
         for (int tas = c.TA; tas >= 1; tas = (tas == 1 ? 0 : 1)) {
             const int kgcap = (c.TB * tas == 1) ? 16 : 8;
             for (int kg = (c.Cin_g < kgcap ? c.Cin_g : kgcap); kg >= 1; --kg) {

@@ -35,6 +35,7 @@ int mfc_set_async_on_lane(int k);
 int mfc_set_own_main(int v);
 int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
+int mfc_conv_set_fill_pct(int v);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
@@ -52,6 +53,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 15) return mfc_set_skip_kinds(value);
     if (id == 16) return mfc_set_async_prio(value);
     if (id == 17) { g_wgrad_deep = value; return 0; }
+    if (id == 18) return mfc_conv_set_fill_pct(value);
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
