@@ -36,7 +36,7 @@ def synth(B, T, H, W, nc, seed, device):
     return frames, mask
 
 
-def pmc_traffic(NT, MT, PM, args):
+def pmc_traffic(NT, MT, PM, NW, args):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_round.sh: two separate
     rocprofv3 --pmc runs of this command, FETCH_SIZE doubled per MI355X_MICROARCH.md; condensed by
     tools/summarize_profile.py).  bench.py cannot collect counters itself; null when no profile matches the configuration."""
@@ -47,7 +47,7 @@ def pmc_traffic(NT, MT, PM, args):
     with open(path) as f:
         ks = json.load(f)["kernels"]
     for name, v in ks.items():
-        if "conv_igemm_kernel" in name and f"Li{NT}ELi{MT}ELi{PM}E" in name and "DF16b" in name:
+        if "conv_igemm_kernel" in name and f"Li{NT}ELi{MT}ELi{PM}ELi{NW}E" in name and "DF16b" in name:
             return v["hbm_bytes_per_launch"], f"profiles/{tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial`)"
     return None, None
 
@@ -140,6 +140,8 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_CONV_NW8"):              # weight (%) of the 8-wave conv geometries in the search (0 = never); before the plan is built
+        L.lib.mfc_set_flag(19, int(os.environ["MFC_CONV_NW8"]))
     if os.environ.get("MFC_CONV_FILL_PCT"):         # before the plan is built (the packed weight layouts depend on the geometry)
         L.lib.mfc_set_flag(18, int(os.environ["MFC_CONV_FILL_PCT"]))
     if os.environ.get("MFC_CONV_GRID"):             # before the plan is built (sizes nothing, but the layouts are queried then)
@@ -188,9 +190,9 @@ def main():
     if rank == 0:
         # dominant kernel = the conv_igemm instantiation (one profiler bucket per <NT, MT, PMAX>, as rocprof names them) with the
         # largest total time in the profiled step; bucket layout: include/mfcnet_hip.h (mfc_prof_result)
-        dt_base = 32 if args.dtype == "bf16" else 0
+        dt_base = 64 if args.dtype == "bf16" else 0
         roof = None
-        conv = [(dt_base + s, s) for s in range(20)]
+        conv = [(dt_base + s, s) for s in range(40)]
         live = [(b, s) for b, s in conv if prof.launches[b]]
         if live:
             best, bslot = max(live, key=lambda bs: prof.ms[bs[0]])
@@ -198,15 +200,16 @@ def main():
             avg_ms = prof.ms[best] / n
             achieved = prof.flops[best] / n / (avg_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
-            NT = NT_SLOTS[bslot // 4]
+            NW = 8 if bslot >= 20 else 4
+            NT = NT_SLOTS[(bslot % 20) // 4]
             MT, PM = [(4, 3), (4, 6), (2, 4), (2, 10)][bslot % 4]
-            kname = f"conv_igemm_kernel<{'__bf16' if args.dtype == 'bf16' else 'float'}, {NT}, {MT}, {PM}>"
+            kname = f"conv_igemm_kernel<{'__bf16' if args.dtype == 'bf16' else 'float'}, {NT}, {MT}, {PM}, {NW}>"
             fam_ms = sum(prof.ms[b] for b, _ in conv)
             fam_fl = sum(prof.flops[b] for b, _ in conv)
-            wgb = [64 + dt_base + s for s in range(32)]
+            wgb = [128 + dt_base + s for s in range(64)]
             wg_ms = sum(prof.ms[b] for b in wgb)
             wg_fl = sum(prof.flops[b] for b in wgb)
-            traffic, tsrc = pmc_traffic(NT, MT, PM, args)
+            traffic, tsrc = pmc_traffic(NT, MT, PM, NW, args)
             roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(prof.bytes[best] / n),

@@ -93,7 +93,7 @@ int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream);
  * (slot = (row-in-group, tap column, granule-in-chunk)): the weights of one (tap-row group, channel chunk, cout block) stage are one contiguous block that is DMA-copied
  * straight into LDS.  The blocking depends on the launch geometry, so the packer asks for it here.      */
 typedef struct { int32_t KG, nchunks, NT16, Yblocks, nslots, TA, TB, lds_bytes; int64_t bytes;
-                 int32_t MT, TH, TW, grid, per_block, TAS; } mfc_conv_layout;   /* last row: launch geometry (informational) */
+                 int32_t MT, TH, TW, grid, per_block, TAS, NW, pad_; } mfc_conv_layout;   /* last row: launch geometry (informational; NW = waves per workgroup) */
 int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
 /* LDS bytes a launch of `d` needs (for tests / planners); <0 on invalid desc. */
 int mfc_conv2d_lds_bytes(const mfc_conv_desc* d);
@@ -384,11 +384,12 @@ int mfc_program_profile(const mfc_op* ops, int32_t n, int32_t reps, float* ms_ou
 /* In-process kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
  * While enabled, every conv forward/dgrad and wgrad launch is bracketed by two events; mfc_prof_collect
  * synchronises and sums elapsed time, launches and algorithmic FLOPs per bucket.
- * bucket = family*64 + dtype*32 + slot (dtype 0 = fp32, 1 = bf16);
+ * bucket = family*128 + dtype*64 + slot (dtype 0 = fp32, 1 = bf16);
  *   family 0 = conv_igemm_kernel<T, NT, MT, PMAX>: slot = ntIndex*4 + variant, NT in {1,2,3,4,6} -> ntIndex 0..4,
- *              variant 0..3 = <MT,PMAX> in {<4,3>, <4,6>, <2,4>, <2,10>}   (one bucket per kernel instantiation, as rocprof sees it)
+ *              variant 0..3 = <MT,PMAX> in {<4,3>, <4,6>, <2,4>, <2,10>}, +20 for the 8-wave instantiations (NW = 8)
+ *              (one bucket per kernel instantiation, as rocprof sees it)
  *   family 1 = weight gradient: slot 0..2 generic kernel (TPW 8/16/28), 8..10 fast kernel (TB 1/3/11), 16..17 wave kernel (TB 3/11) */
-#define MFC_PROF_BUCKETS 128
+#define MFC_PROF_BUCKETS 256
 typedef struct { double ms[MFC_PROF_BUCKETS]; double flops[MFC_PROF_BUCKETS]; double bytes[MFC_PROF_BUCKETS]; int64_t launches[MFC_PROF_BUCKETS]; } mfc_prof_result;
 int mfc_prof_enable(int on);
 int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded events, fills `out`, clears the log */

@@ -51,8 +51,11 @@ __device__ inline float row16_sum(float v) {
     return v;
 }
 
-template <typename T, int NT, int MT, int PMAX>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
+// NW = waves per workgroup: 4 (two workgroups per CU, 80 KiB LDS each) or 8 (ONE workgroup per CU with the whole 160 KiB: the
+// weight stage is shared by twice the waves, so the channel chunk doubles and the number of stages -- each with its fixed
+// prefetch-issue / barrier cost -- halves)
+template <typename T, int NT, int MT, int PMAX, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(ConvK p) {
     constexpr int E = Gran<T>::E;
     constexpr bool BF = (E == 8);
     constexpr int NT16 = NT * 16;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
     }
     // patch pieces this thread stages: granule p_gi of pixels tid/KGP + i*pstep  (py<<16|px, or -1)
     int KGP = 1; while (KGP < kg) KGP <<= 1;
-    const int p_gi = tid & (KGP - 1), pstep = 256 / KGP;
+    const int p_gi = tid & (KGP - 1), pstep = (NW * 64) / KGP;
     int pyx[PMAX];
     // FA ("fast addressing", variants with register slack): per piece the byte offset from the first patch pixel of an interior
     // tile (pgo) and the LDS byte offset (plo, a dummy slot for pieces that carry nothing), so that the prefetch of an interior
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         // drains it (s_waitcnt vmcnt(0)) before the compute loop, i.e. no overlap.  The buffers are disjoint by
         // construction (double buffer); completion is awaited explicitly (dma_wait) before the stage-end barrier.
         const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wl;
-        for (int piece = wave; piece < p.npieces; piece += 4) {
+        for (int piece = wave; piece < p.npieces; piece += NW) {
             const char* g = src + piece * 1024;
             const unsigned ldst = __builtin_amdgcn_readfirstlane(lbase + piece * 1024);
             unsigned keep;
@@ -265,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
                 const float sa = row16_sum(ssum[nt][r]), sb = row16_sum(ssq[nt][r]);
                 ssum[nt][r] = 0.f; ssq[nt][r] = 0.f;
                 if ((lane & 15) == 0) {
-                    red[red_par * 8 * NT16 + (wave * 2 + 0) * NT16 + nt * 16 + cq + r] = sa;
-                    red[red_par * 8 * NT16 + (wave * 2 + 1) * NT16 + nt * 16 + cq + r] = sb;
+                    red[red_par * 2 * NW * NT16 + (wave * 2 + 0) * NT16 + nt * 16 + cq + r] = sa;
+                    red[red_par * 2 * NW * NT16 + (wave * 2 + 1) * NT16 + nt * 16 + cq + r] = sb;
                 }
             }
         red_pending = true; red_n0 = n0; red_grp = grp; red_rep = rep; red_par ^= 1;
@@ -275,9 +278,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvK p) {
         if (tid < 2 * NT16) {
             const int which = tid / NT16, cl = tid - which * NT16;
             if (red_n0 + cl < p.Cout_p) {
-                const float* rd = red + (red_par ^ 1) * 8 * NT16;
-                float s = rd[(0 * 2 + which) * NT16 + cl] + rd[(1 * 2 + which) * NT16 + cl] +
-                          rd[(2 * 2 + which) * NT16 + cl] + rd[(3 * 2 + which) * NT16 + cl];
+                const float* rd = red + (red_par ^ 1) * 2 * NW * NT16;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += rd[(w * 2 + which) * NT16 + cl];
                 atomicAdd(p.out_stats + (((size_t)red_rep * p.G + red_grp) * 2 + which) * p.Cout_p + red_n0 + cl, s);
             }
         }
@@ -560,7 +564,10 @@ int mfc_conv_set_ablate(int v) { g_conv_ablate = v; return 0; }
 static int g_conv_grid = 512;        // persistent workgroups per launch (2 per CU); tuning: mfc_set_flag(4, n)
 int mfc_conv_set_grid(int v) { g_conv_grid = v > 0 ? v : 512; return 0; }
 
-static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid) {
+static int g_conv_nw8 = 100;          // 8-wave (one workgroup per CU) geometries: score weight in % (0 = never); tuning: mfc_set_flag(19, pct)
+int mfc_conv_set_nw8(int v) { g_conv_nw8 = v; return 0; }
+
+static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid, int& NWsel) {
     if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
     if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
     const int E = d->dtype == MFC_BF16 ? 8 : 4;
@@ -588,14 +595,18 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     // Search the launch geometry: pixel tile (256 or 128 pixels), tap rows per stage (all or one) and channel chunk KG,
     // subject to LDS <= 80 KiB (2 workgroups per CU) and the per-thread patch-piece budget; prefer the most MFMAs per
     // stage (fewer barriers / less per-stage bookkeeping per MFMA), discounted by padding waste.
-    double best_score = -1; ConvK bk = k; int bMT = 2, bPM = 0; size_t blds = 0;
+    double best_score = -1; ConvK bk = k; int bMT = 2, bPM = 0, bNW = 4; size_t blds = 0;
+    for (int nwi = 0; nwi < 2; ++nwi) {
+    const int nw = nwi == 0 ? 4 : 8;
+    if (nw == 8 && (g_conv_nw8 <= 0 || E != 8)) continue;
+    const int slots = nw == 8 ? g_conv_grid / 2 : g_conv_grid;          // resident workgroups on the chip
     for (int mi = 0; mi < 2; ++mi) {
         const int mt = mi == 0 ? 4 : 2;
         if (g_conv_force_mt && mt != g_conv_force_mt) continue;
-        const int cap = 64 * mt;
+        const int cap = nw * 16 * mt;
         ConvK c = k; double eff;
         if (d->TH > 0 && d->TW > 0) {
-            if (d->TH * d->TW > cap || (mt == 4 && d->TH * d->TW <= 128)) continue;
+            if (d->TH * d->TW > cap || (mt == 4 && d->TH * d->TW <= cap / 2)) continue;
             c.TH = d->TH; c.TW = d->TW;
             eff = (double)d->Hl * d->Wl / ((double)ceil_div(d->Hl, c.TH) * ceil_div(d->Wl, c.TW) * cap);
         } else {
@@ -605,7 +616,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
         c.PH = (c.TH - 1) * c.s + c.TA; c.PW = (c.TW - 1) * c.s + c.TB;
         const long units = (long)c.N * c.tilesY * c.tilesX * c.Yblocks;
         // parallelism: a launch wants >= ~2 units per CU-slot (512 slots); fewer units -> idle CUs
-        const double fill = units >= 512 ? 1.0 : pow((double)units / 512.0, g_conv_fill_pct / 100.0);
+        const double fill = units >= slots ? 1.0 : pow((double)units / (double)slots, g_conv_fill_pct / 100.0);
         for (int tas = c.TA; tas >= 1; tas = (tas == 1 ? 0 : 1)) {
             const int kgcap = (c.TB * tas == 1) ? 16 : 8;
             for (int kg = (c.Cin_g < kgcap ? c.Cin_g : kgcap); kg >= 1; --kg) {
@@ -626,21 +637,24 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
                 t.off_w1 = t.off_w0 + (int)wbytes;
                 t.off_ktab = t.off_w1 + (int)wbytes;
                 t.off_red = t.off_ktab + ((t.nslots * 4 + 15) & ~15);
-                t.off_dummy = t.off_red + 2 * 4 * 2 * NT * 16 * 4;
+                t.off_dummy = t.off_red + 2 * nw * 2 * NT * 16 * 4;
                 const size_t l = (size_t)t.off_dummy + 16;
-                const int pm = ceil_div(t.PH * t.PW, 256 / KGP);
+                const int pm = ceil_div(t.PH * t.PW, (nw * 64) / KGP);
                 // register budget (no spills: a spill in the prefetch path serialises it): wide N tiles keep fewer
                 // pixel tiles / prefetch pieces per thread
                 int pm_max = mt == 4 ? (NT == 6 ? 0 : NT == 4 ? 3 : 6) : (NT == 6 ? 4 : 10);
-                if (l > (size_t)g_conv_lds_kb * 1024 || pm > pm_max || t.nslots > 256) continue;
+                if (nw == 8) pm_max = mt == 4 ? (NT == 6 ? 0 : 3) : 4;          // (the 8-wave instantiations: <MT 4, PMAX 3> and <MT 2, PMAX 4>)
+                const size_t lds_cap = nw == 8 ? (size_t)156 * 1024 : (size_t)g_conv_lds_kb * 1024;
+                if (l > lds_cap || pm > pm_max || t.nslots > 256) continue;
                 const double mf = (E == 8 ? t.nslots / 4 : t.nslots) * mt * NT;      // MFMAs per wave per stage
-                const double score = eff * fill * ((double)real / t.nslots) * (mf / (mf + 40.0)) * (mt == 4 ? 1.0 : 0.93);
-                if (score > best_score) { best_score = score; bk = t; bMT = mt; bPM = pm; blds = l; }
+                const double score = eff * fill * ((double)real / t.nslots) * (mf / (mf + 40.0)) * (mt == 4 ? 1.0 : 0.93) * (nw == 8 ? g_conv_nw8 / 100.0 : 1.0);
+                if (score > best_score) { best_score = score; bk = t; bMT = mt; bPM = pm; blds = l; bNW = nw; }
             }
         }
     }
+    }
     const bool ok = best_score > 0;
-    k = bk; MT = bMT; PM = bPM; lds = blds;
+    k = bk; MT = bMT; PM = bPM; lds = blds; NWsel = bNW;
     if (!ok) return MFC_ERR_UNSUPPORTED;
     k.ntiles = k.N * k.tilesY * k.tilesX;
     k.nunits = k.ntiles * k.Yblocks;
@@ -649,78 +663,90 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
         const double in_bytes = (double)k.N * k.Hin * k.Win * k.Cin_p * (d->dtype == MFC_BF16 ? 2.0 : 4.0);
         k.ybfast = g_conv_ybfast >= 0 ? (g_conv_ybfast && k.Yblocks > 1) : (k.Yblocks > 1 && in_bytes * (k.Yblocks - 1) > 128e6);
     }
-    grid = g_conv_grid;
+    grid = NWsel == 8 ? g_conv_grid / 2 : g_conv_grid;
     if (grid > k.nunits) grid = k.nunits;
     k.per_block = ceil_div(k.nunits, grid);
     grid = ceil_div(k.nunits, k.per_block);
     return MFC_OK;
 }
 
-template <typename T, int NT, int MT, int PMAX>
+template <typename T, int NT, int MT, int PMAX, int NW>
 static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT, MT, PMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT, MT, PMAX, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on) {
         const int nti = NT == 1 ? 0 : NT == 2 ? 1 : NT == 3 ? 2 : NT == 4 ? 3 : 4;
-        const int slot = nti * 4 + (MT == 4 ? (PMAX == 3 ? 0 : 1) : (PMAX == 4 ? 2 : 3));
+        const int slot = nti * 4 + (MT == 4 ? (PMAX == 3 ? 0 : 1) : (PMAX == 4 ? 2 : 3)) + (NW == 8 ? 20 : 0);
         const double E = sizeof(T) == 2 ? 8.0 : 4.0;
         const double flops = 2.0 * k.N * k.Hl * k.Wl * (double)k.Cout * k.TA * k.TB * (k.Cin_g * E);
         const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_g * 16.0) / (k.osh * k.osw) + (double)k.N * k.Hl * k.Wl * k.Cout_p * sizeof(T);
-        mfc_prof_before(st, 0 * 64 + (sizeof(T) == 2 ? 32 : 0) + slot, flops, bytes);
+        mfc_prof_before(st, 0 * 128 + (sizeof(T) == 2 ? 64 : 0) + slot, flops, bytes);
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT, PMAX>), dim3(grid), dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT, PMAX, NW>), dim3(grid), dim3(NW * 64), lds, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
 
 extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
-    ConvK k; int NT, MT, PM, grid; size_t lds;
+    ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     mfc_conv_desc t = *d;
     if (!t.in) t.in = (const void*)16;
     if (!t.wp) t.wp = (const void*)16;
     if (!t.out) t.out = (void*)16;
-    int rc = conv_setup(&t, k, NT, MT, PM, lds, grid);
+    int rc = conv_setup(&t, k, NT, MT, PM, lds, grid, NW);
     if (rc < 0 || !out) return rc < 0 ? rc : MFC_ERR_INVALID_ARG;
     out->KG = k.KG; out->nchunks = k.nchunks; out->NT16 = NT * 16; out->Yblocks = k.Yblocks; out->nslots = k.nslots;
     out->TA = k.TA; out->TB = k.TB; out->lds_bytes = (int32_t)lds; out->TAS = k.TAS;
     out->bytes = (int64_t)k.nstg * k.nchunks * k.Yblocks * k.stage_bytes;
-    out->MT = MT; out->TH = k.TH; out->TW = k.TW; out->grid = grid; out->per_block = k.per_block;
+    out->MT = MT; out->TH = k.TH; out->TW = k.TW; out->grid = grid; out->per_block = k.per_block; out->NW = NW;
     return MFC_OK;
 }
 
 extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
-    ConvK k; int NT, MT, PM, grid; size_t lds;
-    int rc = conv_setup(d, k, NT, MT, PM, lds, grid);
+    ConvK k; int NT, MT, PM, grid, NW; size_t lds;
+    int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
     return rc < 0 ? rc : (int)lds;
 }
 
 template <typename T, int NT>
-static int conv_dispatch(const ConvK& k, int MT, int PM, size_t lds, int grid, hipStream_t st) {
+static int conv_dispatch(const ConvK& k, int MT, int PM, int NW, size_t lds, int grid, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (NW == 8) {       // one workgroup per CU (bf16 only)
+            if constexpr (NT == 6) {
+                if (MT == 2 && PM <= 4) return conv_launch<T, NT, 2, 4, 8>(k, lds, grid, st);
+                return MFC_ERR_UNSUPPORTED;
+            } else {
+                if (MT == 4 && PM <= 3) return conv_launch<T, NT, 4, 3, 8>(k, lds, grid, st);
+                if (MT == 2 && PM <= 4) return conv_launch<T, NT, 2, 4, 8>(k, lds, grid, st);
+                return MFC_ERR_UNSUPPORTED;
+            }
+        }
+    }
     if constexpr (NT == 6) {
-        if (MT == 2 && PM <= 4) return conv_launch<T, NT, 2, 4>(k, lds, grid, st);
+        if (MT == 2 && PM <= 4) return conv_launch<T, NT, 2, 4, 4>(k, lds, grid, st);
         return MFC_ERR_UNSUPPORTED;
     } else {
         if (MT == 4) {
-            if (PM <= 3) return conv_launch<T, NT, 4, 3>(k, lds, grid, st);
-            if constexpr (NT <= 3) { if (PM <= 6) return conv_launch<T, NT, 4, 6>(k, lds, grid, st); }
+            if (PM <= 3) return conv_launch<T, NT, 4, 3, 4>(k, lds, grid, st);
+            if constexpr (NT <= 3) { if (PM <= 6) return conv_launch<T, NT, 4, 6, 4>(k, lds, grid, st); }
             return MFC_ERR_UNSUPPORTED;
         }
-        if (PM <= 4) return conv_launch<T, NT, 2, 4>(k, lds, grid, st);
-        return conv_launch<T, NT, 2, 10>(k, lds, grid, st);
+        if (PM <= 4) return conv_launch<T, NT, 2, 4, 4>(k, lds, grid, st);
+        return conv_launch<T, NT, 2, 10, 4>(k, lds, grid, st);
     }
 }
 
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
-    ConvK k; int NT, MT, PM, grid; size_t lds;
-    int rc = conv_setup(d, k, NT, MT, PM, lds, grid);
+    ConvK k; int NT, MT, PM, grid, NW; size_t lds;
+    int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
     if (rc < 0) return rc;
     hipStream_t st = (hipStream_t)stream;
 #define MFC_CONV_CASE(nt) \
-    case nt: return d->dtype == MFC_BF16 ? conv_dispatch<bf16_t, nt>(k, MT, PM, lds, grid, st) : conv_dispatch<float, nt>(k, MT, PM, lds, grid, st);
+    case nt: return d->dtype == MFC_BF16 ? conv_dispatch<bf16_t, nt>(k, MT, PM, NW, lds, grid, st) : conv_dispatch<float, nt>(k, MT, PM, NW, lds, grid, st);
     switch (NT) {
         MFC_CONV_CASE(1) MFC_CONV_CASE(2) MFC_CONV_CASE(3) MFC_CONV_CASE(4) MFC_CONV_CASE(6)
     }

@@ -36,6 +36,7 @@ int mfc_set_own_main(int v);
 int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
+int mfc_conv_set_nw8(int v);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
@@ -54,6 +55,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 16) return mfc_set_async_prio(value);
     if (id == 17) { g_wgrad_deep = value; return 0; }
     if (id == 18) return mfc_conv_set_fill_pct(value);
+    if (id == 19) return mfc_conv_set_nw8(value);
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
@@ -825,7 +827,7 @@ static int wgrad_launch(const WgradK& k, size_t lds, int Y, hipStream_t st) {
         const int slot = TPW == 8 ? 0 : TPW == 16 ? 1 : 2;
         const double flops = 2.0 * k.N * k.Hout * k.Wout * (double)k.Co16 * k.Ci16 * k.TA * k.TB;
         const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_p + (double)k.N * k.Hout * k.Wout * k.Cout_p) * sizeof(T);
-        mfc_prof_before(st, 1 * 64 + (sizeof(T) == 2 ? 32 : 0) + slot, flops, bytes);
+        mfc_prof_before(st, 1 * 128 + (sizeof(T) == 2 ? 64 : 0) + slot, flops, bytes);
     }
     hipLaunchKernelGGL((conv_wgrad_kernel<T, TPW, TR>), dim3(k.splits, Y), dim3(256), lds, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);
@@ -843,7 +845,7 @@ static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st)
     if (g_mfc_prof_on) {
         const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB;
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
-        mfc_prof_before(st, 1 * 64 + 32 + 8 + (TB == 1 ? 0 : TB == 3 ? 1 : 2), flops, bytes);
+        mfc_prof_before(st, 1 * 128 + 64 + 8 + (TB == 1 ? 0 : TB == 3 ? 1 : 2), flops, bytes);
     }
     hipLaunchKernelGGL((conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>), dim3(f.splits * Y), dim3(256), lds, st, f);
     if (g_mfc_prof_on) mfc_prof_after(st);
@@ -925,7 +927,7 @@ static int wgrad_wave_launch(const WgradW& f, const WgradBatch& tb, size_t lds, 
     if (g_mfc_prof_on) {
         const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB * tb.n;
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0 * tb.n;
-        mfc_prof_before(st, 1 * 64 + 32 + 16 + (TB == 3 ? 0 : 1), flops, bytes);
+        mfc_prof_before(st, 1 * 128 + 64 + 16 + (TB == 3 ? 0 : 1), flops, bytes);
     }
     hipLaunchKernelGGL((conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP, PF>), dim3(f.splits * Y * tb.n), dim3(256), lds, st, f, tb);
     if (g_mfc_prof_on) mfc_prof_after(st);

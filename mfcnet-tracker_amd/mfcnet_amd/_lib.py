@@ -48,7 +48,7 @@ class PackJob(C.Structure):
 class ConvLayout(C.Structure):
     _fields_ = [("KG", i32), ("nchunks", i32), ("NT16", i32), ("Yblocks", i32), ("nslots", i32), ("TA", i32), ("TB", i32),
                 ("lds_bytes", i32), ("bytes", C.c_int64), ("MT", i32), ("TH", i32), ("TW", i32), ("grid", i32),
-                ("per_block", i32), ("TAS", i32)]
+                ("per_block", i32), ("TAS", i32), ("NW", i32), ("pad_", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -111,7 +111,7 @@ class LossDesc(C.Structure):
 
 
 class ProfResult(C.Structure):
-    _fields_ = [("ms", C.c_double * 128), ("flops", C.c_double * 128), ("bytes", C.c_double * 128), ("launches", C.c_int64 * 128)]
+    _fields_ = [("ms", C.c_double * 256), ("flops", C.c_double * 256), ("bytes", C.c_double * 256), ("launches", C.c_int64 * 256)]
 
 
 class RawOp(C.Structure):
