@@ -564,7 +564,7 @@ int mfc_conv_set_ablate(int v) { g_conv_ablate = v; return 0; }
 static int g_conv_grid = 512;        // persistent workgroups per launch (2 per CU); tuning: mfc_set_flag(4, n)
 int mfc_conv_set_grid(int v) { g_conv_grid = v > 0 ? v : 512; return 0; }
 
-static int g_conv_nw8 = 100;          // 8-wave (one workgroup per CU) geometries: score weight in % (0 = never); tuning: mfc_set_flag(19, pct)
+static int g_conv_nw8 = 90;           // 8-wave (one workgroup per CU) geometries: score weight in % (0 = never; 90 sends ties to the 4-wave form); tuning: mfc_set_flag(19, pct)
 int mfc_conv_set_nw8(int v) { g_conv_nw8 = v; return 0; }
 
 static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid, int& NWsel) {
