@@ -297,19 +297,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
     __syncthreads();
 
     if (p.ablate & 32) return;
+    const bool resident = (p.nchunks == 1 && p.nstg == 1 && p.Yblocks == 1);
     int tl = 0, c = 0, a = 0;          // current stage coordinates (a = tap-row group)
     for (int g = 0; g < total; ++g) {
         int tl2 = tl, c2 = c, a2 = a + 1;
         if (a2 == p.nstg) { a2 = 0; ++c2; if (c2 == p.nchunks) { c2 = 0; ++tl2; uc2 = uc_next(uc); } }
         const bool nxt = (g + 1 < total);
         const bool newpatch = nxt && (a2 == 0) && (p.nchunks > 1 || tl2 != tl);
-        if (nxt && !(p.ablate & 1)) dma_w(uc2, c2, a2, smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
+        // (single-stage launches with one cout block use the same weights for every tile: they stay in buffer 0)
+        if (nxt && !resident && !(p.ablate & 1)) dma_w(uc2, c2, a2, smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
         if (newpatch && !(p.ablate & 2)) load_patch(uc2, c2);
         if (red_pending) stats_flush();
 
         // ---------------- compute stage (tl, c, a) ----------------
         {
-            const char* wl = smem + ((g & 1) ? p.off_w1 : p.off_w0);
+            const char* wl = smem + (((g & 1) && !resident) ? p.off_w1 : p.off_w0);
             const char* pa = patch + a * p.TAS * p.PW * p.pitch;
             if constexpr (BF) {
                 // Software-pipelined, ping-pong unrolled by two: the LDS fragment reads of k-step k+1 are issued before the
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
             __syncthreads();           // every wave has finished reading the current patch
             if (!(p.ablate & 2)) store_patch();
         }
-        dma_wait();                    // the weight DMA of stage g+1 has landed (this wave's pieces) ...
+        if (!resident) dma_wait();     // the weight DMA of stage g+1 has landed (this wave's pieces) ...
         __syncthreads();               // ... and everybody's
         tl = tl2; c = c2; a = a2; uc = uc2;
     }
