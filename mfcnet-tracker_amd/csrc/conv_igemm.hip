@@ -39,6 +39,7 @@ struct ConvK {
     int off_w0, off_w1, off_ktab, off_red;   // LDS offsets (bytes)
     int off_dummy;                           // 16-byte LDS slot dead staging pieces are stored to
     int ybfast;                              // unit order: 1 = cout block fastest (the Yblocks units of a pixel tile run back to back on one workgroup: the re-reads of the tile hit L2 instead of HBM)
+    int wres;                                // >0: single-stage launch whose Yblocks weight stages ALL stay in LDS (wres = Yblocks); the pixel tile is staged once for its Yblocks units
     int ablate;                              // tuning only: 1 skip weight DMA, 2 skip patch staging, 4 skip output stores, 8 skip MFMAs
 };
 
@@ -290,20 +291,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
 
     // ---------------- prologue ----------------
     UC uc = uc_init(u0), uc2 = uc;
-    dma_w(uc, 0, 0, smem + p.off_w0);
+    const int wstride = p.npieces * 1024;
+    if (p.wres) {
+        for (int yb = 0; yb < p.wres; ++yb) { UC t = uc; t.yb = yb; dma_w(t, 0, 0, smem + p.off_w0 + yb * wstride); }
+    } else {
+        dma_w(uc, 0, 0, smem + p.off_w0);
+    }
     load_patch(uc, 0);
     store_patch();
     dma_wait();
     __syncthreads();
 
     if (p.ablate & 32) return;
-    const bool resident = (p.nchunks == 1 && p.nstg == 1 && p.Yblocks == 1);
+    const bool resident = (p.nchunks == 1 && p.nstg == 1 && p.Yblocks == 1) || p.wres;
     int tl = 0, c = 0, a = 0;          // current stage coordinates (a = tap-row group)
     for (int g = 0; g < total; ++g) {
         int tl2 = tl, c2 = c, a2 = a + 1;
         if (a2 == p.nstg) { a2 = 0; ++c2; if (c2 == p.nchunks) { c2 = 0; ++tl2; uc2 = uc_next(uc); } }
         const bool nxt = (g + 1 < total);
-        const bool newpatch = nxt && (a2 == 0) && (p.nchunks > 1 || tl2 != tl);
+        const bool newpatch = nxt && (a2 == 0) && (p.nchunks > 1 || (p.wres ? uc2.yb == 0 : tl2 != tl));
         // (single-stage launches with one cout block use the same weights for every tile: they stay in buffer 0)
         if (nxt && !resident && !(p.ablate & 1)) dma_w(uc2, c2, a2, smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
         if (newpatch && !(p.ablate & 2)) load_patch(uc2, c2);
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
 
         // ---------------- compute stage (tl, c, a) ----------------
         {
-            const char* wl = smem + (((g & 1) && !resident) ? p.off_w1 : p.off_w0);
+            const char* wl = smem + (p.wres ? p.off_w0 + uc.yb * wstride : (((g & 1) && !resident) ? p.off_w1 : p.off_w0));
             const char* pa = patch + a * p.TAS * p.PW * p.pitch;
             if constexpr (BF) {
                 // Software-pipelined, ping-pong unrolled by two: the LDS fragment reads of k-step k+1 are issued before the
@@ -557,6 +563,7 @@ static int g_conv_force_mt = 0;      // tuning: mfc_set_flag(2, 2|4)
 int mfc_conv_set_force_mt(int v) { g_conv_force_mt = v; return 0; }
 static int g_conv_lds_kb = 80;       // LDS budget per workgroup (80 KiB -> 2 workgroups per CU); tuning: mfc_set_flag(6, kb)
 int mfc_conv_set_lds_kb(int v) { g_conv_lds_kb = v > 0 ? v : 80; return 0; }
+int g_conv_wres = 1;                 // keep all cout blocks' weights of a single-stage launch in LDS; tuning: mfc_set_flag(20, v)
 static int g_conv_ybfast = -1;        // -1 auto, 0 never, 1 always; tuning: mfc_set_flag(8, v)
 int mfc_conv_set_ybfast(int v) { g_conv_ybfast = v; return 0; }
 static int g_conv_fill_pct = 100;     // exponent (in %) on the under-fill penalty of the geometry search; tuning: mfc_set_flag(18, pct)
@@ -664,6 +671,18 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     {   // cout-block-fastest order when the Yblocks passes over the input would otherwise each stream it from HBM again
         const double in_bytes = (double)k.N * k.Hin * k.Win * k.Cin_p * (d->dtype == MFC_BF16 ? 2.0 : 4.0);
         k.ybfast = g_conv_ybfast >= 0 ? (g_conv_ybfast && k.Yblocks > 1) : (k.Yblocks > 1 && in_bytes * (k.Yblocks - 1) > 128e6);
+    }
+    k.wres = 0;
+    if (g_conv_wres && k.nchunks == 1 && k.nstg == 1 && k.Yblocks > 1) {
+        // every cout block's weights fit next to the patch: keep them all in LDS and stage each pixel tile once
+        const int wb = k.npieces * 1024;
+        const int ktab = k.off_w0 + k.Yblocks * wb, redo = ktab + (k.off_red - k.off_ktab), dum = redo + (k.off_dummy - k.off_red);
+        const size_t cap = NWsel == 8 ? (size_t)156 * 1024 : (size_t)g_conv_lds_kb * 1024;
+        if ((size_t)dum + 16 <= cap) {
+            k.wres = k.Yblocks; k.ybfast = 1;
+            k.off_ktab = ktab; k.off_red = redo; k.off_dummy = dum;
+            if ((size_t)dum + 16 > lds) lds = (size_t)dum + 16;
+        }
     }
     grid = NWsel == 8 ? g_conv_grid / 2 : g_conv_grid;
     if (grid > k.nunits) grid = k.nunits;

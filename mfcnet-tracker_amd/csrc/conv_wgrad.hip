@@ -37,6 +37,7 @@ int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
+extern int g_conv_wres;
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
@@ -56,6 +57,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 17) { g_wgrad_deep = value; return 0; }
     if (id == 18) return mfc_conv_set_fill_pct(value);
     if (id == 19) return mfc_conv_set_nw8(value);
+    if (id == 20) { g_conv_wres = value; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }

@@ -43,6 +43,7 @@ CONV_CASES = [  # N, Cin, Cout, k, s, H, W
     (2, 384, 384, 3, 1, 15, 20), (2, 256, 64, 1, 1, 16, 24), (1, 720, 720, 1, 1, 12, 20), (2, 720, 5, 1, 1, 16, 24),
     (2, 15, 15, 11, 1, 32, 48), (1, 22, 15, 11, 1, 24, 40), (2, 15, 5, 1, 1, 16, 16), (1, 48, 96, 3, 2, 23, 30),
     (2, 32, 32, 3, 1, 30, 40), (1, 128, 256, 3, 2, 30, 40), (2, 192, 48, 1, 1, 8, 10),
+    (3, 64, 256, 1, 1, 40, 56), (2, 32, 96, 3, 1, 24, 40),      # single-stage launches with several cout blocks (weights of all blocks resident)
 ]
 
 
@@ -62,12 +63,14 @@ def test_conv_fwd(M, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_conv_fused_bn_relu_input_and_stats(M, dtype):
+@pytest.mark.parametrize("cfg", [(48, 96, 3, 20, 28), (64, 256, 1, 40, 56)])
+def test_conv_fused_bn_relu_input_and_stats(M, dtype, cfg):
     """consumer-side BN-apply+ReLU (zero padding AFTER the transform) and the epilogue statistics."""
     _, L, ops = M
-    N, Cin, Cout, H, W, G = 4, 48, 96, 20, 28, 2
+    Cin, Cout, k, H, W = cfg
+    N, G = 4, 2
     x = rnd(dtype, N, Cin, H, W, seed=4)
-    w = rnd(dtype, Cout, Cin, 3, 3, seed=5, scale=0.05)
+    w = rnd(dtype, Cout, Cin, k, k, seed=5, scale=0.05)
     scale = torch.rand(G, Cin) + 0.5
     shift = torch.randn(G, Cin) * 0.3
     coef = torch.zeros(G, 4, Cin)
@@ -75,9 +78,9 @@ def test_conv_fused_bn_relu_input_and_stats(M, dtype):
     xa = torch.cat([F.relu(x[g * 2:(g + 1) * 2] * scale[g].view(1, -1, 1, 1) + shift[g].view(1, -1, 1, 1)) for g in range(G)])
     if dtype == torch.bfloat16:
         xa = xa.bfloat16().float()
-    ref = F.conv2d(xa, w, None, padding=1)
+    ref = F.conv2d(xa, w, None, padding=k // 2)
     stats = torch.zeros(L.STAT_REPLICAS, G, 2, Cout, device="cuda")
-    y = ops.conv2d(ops.to_nhwc(x, dtype), w.cuda(), 3, 1, in_coef=coef.cuda(), in_relu=True, ipg=2, stats=stats)
+    y = ops.conv2d(ops.to_nhwc(x, dtype), w.cuda(), k, 1, in_coef=coef.cuda(), in_relu=True, ipg=2, stats=stats)
     out = ops.to_nchw(y, Cout).cpu()
     assert relerr(out, ref) < TOL[dtype]
     st = stats.sum(0).cpu()
