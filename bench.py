@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+PEAK_HBM_GBPS = 8000.0                              # HBM3E, MI355X_MICROARCH.md
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 NT_SLOTS = [1, 2, 3, 4, 6]
 
@@ -210,8 +211,15 @@ def main():
             wg_ms = sum(prof.ms[b] for b in wgb)
             wg_fl = sum(prof.flops[b] for b in wgb)
             traffic, tsrc = pmc_traffic(NT, MT, PM, NW, args)
-            roof = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            # which roof binds this kernel: its algorithmic bytes at the HBM peak vs its flops at the dense MFMA peak
+            abytes = prof.bytes[best] / n
+            gbps = abytes / (avg_ms * 1e-3) / 1e9
+            hbm_bound = abytes / (PEAK_HBM_GBPS * 1e9) > (prof.flops[best] / n) / (peak * 1e12)
+            roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
+                    "achieved": round(gbps if hbm_bound else achieved, 2), "peak": PEAK_HBM_GBPS if hbm_bound else peak,
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(gbps / PEAK_HBM_GBPS if hbm_bound else achieved / peak, 4),
+                    "mfma_tflops": round(achieved, 2), "mfma_frac": round(achieved / peak, 4),
+                    "hbm_gbps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4),
                     "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(prof.bytes[best] / n),
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": n // max(prof_steps, 1),
                     "flops_per_launch": prof.flops[best] / n,

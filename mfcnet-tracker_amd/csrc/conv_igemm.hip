@@ -643,7 +643,8 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
                 const size_t wbytes = ((size_t)t.stage_bytes + 1023) & ~(size_t)1023;
                 t.npieces = (int)(wbytes / 1024);
                 t.off_w0 = (int)((patch + 1023) & ~(size_t)1023);
-                t.off_w1 = t.off_w0 + (int)wbytes;
+                const bool one_w = (t.nchunks == 1 && t.nstg == 1 && t.Yblocks == 1);      // resident weights: no second buffer
+                t.off_w1 = t.off_w0 + (one_w ? 0 : (int)wbytes);
                 t.off_ktab = t.off_w1 + (int)wbytes;
                 t.off_red = t.off_ktab + ((t.nslots * 4 + 15) & ~15);
                 t.off_dummy = t.off_red + 2 * nw * 2 * NT * 16 * 4;

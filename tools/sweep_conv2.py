@@ -12,7 +12,7 @@ def time_op(op, reps=10):
         rc = L.lib.mfc_program_profile(prog, 1, reps, ms, L.stream_ptr()); assert rc == 0, rc
     return ms[0] * 1e3
 
-SHAPES = [(24, 64, 256, 1, 120, 160), (24, 32, 64, 3, 60, 80), (24, 64, 128, 3, 30, 40), (24, 64, 32, 1, 120, 160), (24, 32, 96, 1, 60, 80), (24, 48, 96, 3, 60, 80), (24, 64, 48, 3, 120, 160)]
+SHAPES = [(24, 32, 32, 3, 120, 160), (24, 18, 18, 3, 120, 160), (24, 48, 48, 3, 120, 160), (24, 32, 64, 3, 60, 80), (24, 64, 32, 1, 120, 160), (24, 32, 96, 1, 60, 80), (8, 15, 15, 3, 480, 640), (8, 15, 15, 11, 480, 640), (24, 64, 256, 1, 120, 160)]
 SHAPES_OLD = [(24, 32, 32, 3, 120, 160), (24, 64, 64, 3, 60, 80), (24, 128, 128, 3, 30, 40), (24, 256, 256, 3, 15, 20), (24, 480, 480, 1, 120, 160), (24, 64, 256, 1, 120, 160), (24, 96, 96, 3, 60, 80), (24, 192, 192, 3, 30, 40), (24, 384, 384, 3, 15, 20), (8, 15, 15, 11, 480, 640), (8, 15, 15, 3, 480, 640)]
 COMBOS = [0, 1]           # flag 20: all cout blocks' weights resident for single-stage launches
 def main():
