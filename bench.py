@@ -188,6 +188,8 @@ def main():
         dt = float(tt)
     final_loss = float(loss.detach())
 
+    cfg_label = ("BASELINE.json configs[2]" if (T, H, W, B) == (3, 480, 640, 8) else
+                 "per-GPU share of BASELINE.json configs[4]" if (T, H, W, B, args.width) == (5, 720, 960, 8, 48) else "custom size")
     if rank == 0:
         # dominant kernel = the conv_igemm instantiation (one profiler bucket per <NT, MT, PMAX>, as rocprof names them) with the
         # largest total time in the profiled step; bucket layout: include/mfcnet_hip.h (mfc_prof_result)
@@ -227,12 +229,12 @@ def main():
                     "all_wgrad_tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms else None,
                     "conv_ms_per_step": round(fam_ms / max(prof_steps, 1), 3), "wgrad_ms_per_step": round(wg_ms / max(prof_steps, 1), 3),
                     "profiled_steps": prof_steps, "profiled_step_streams": "serial"}
-        out = {"metric": "frames/sec (480x640, T=3, HRNet MFCNet) fwd+bwd", "value": round(world * B * T * args.steps / dt, 2),
+        out = {"metric": f"frames/sec ({H}x{W}, T={T}, HRNet MFCNet) fwd+bwd", "value": round(world * B * T * args.steps / dt, 2),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"MFCNet T={T} RGB-only (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, fwd+bwd+Adam "
-                                      f"(BASELINE.json configs[2])", "width": args.width, "global_batch": world * B,
+                                      f"({cfg_label})", "width": args.width, "global_batch": world * B,
                           "frames_per_clip": T, "parallelism": f"dp{world}", "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
