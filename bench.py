@@ -30,21 +30,27 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI
 NT_SLOTS = [1, 2, 3, 4, 6]
 
 
-def synth(B, T, H, W, nc, seed, device):
+def synth(B, T, H, W, nc, seed, device, depth=False, optflow=False):
+    """N(0,1) frames, U[0,1) depth maps, 3*N(0,1) pixel-unit flows (constants), uniform class masks."""
     g = torch.Generator().manual_seed(seed)
     frames = [torch.randn(B, 3, H, W, generator=g).to(device) for _ in range(T)]
     mask = torch.randint(0, nc, (B, H, W), generator=g).to(device)
-    return frames, mask
+    dm = [torch.rand(B, 1, H, W, generator=g).to(device) for _ in range(T)] if depth else None
+    fl = [(3.0 * torch.randn(B, 2, H, W, generator=g)).to(device) for _ in range(T - 1)] if optflow else None
+    return frames, mask, dm, fl
 
 
 def pmc_traffic(NT, MT, PM, NW, args):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_round.sh: two separate
     rocprofv3 --pmc runs of this command, FETCH_SIZE doubled per MI355X_MICROARCH.md; condensed by
     tools/summarize_profile.py).  bench.py cannot collect counters itself; null when no profile matches the configuration."""
-    tag = f"r01_d_w{args.width}_pmc_traffic.json"
-    path = os.path.join(ROOT, "profiles", tag)
-    if args.dtype != "bf16" or (args.batch, args.frames, args.height, args.width_px) != (8, 3, 480, 640) or not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_w{args.width}_pmc_traffic.json")))      # newest round's passes
+    if args.dtype != "bf16" or (args.batch, args.frames, args.height, args.width_px) != (8, 3, 480, 640) or not found \
+            or args.depth or args.optflow or args.basic:
         return None, None
+    path = found[-1]
+    tag = os.path.basename(path)
     with open(path) as f:
         ks = json.load(f)["kernels"]
     for name, v in ks.items():
@@ -83,6 +89,9 @@ def main():
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width-px", type=int, default=640)
+    ap.add_argument("--depth", action="store_true", help="add the T depth maps (BASELINE.json configs[3])")
+    ap.add_argument("--optflow", action="store_true", help="add the T-1 optical-flow fields (BASELINE.json configs[3])")
+    ap.add_argument("--basic", action="store_true", help="model_type HRNetMulti-Basic (flow warp) instead of HRNetMulti-Large")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
@@ -113,18 +122,20 @@ def main():
 
     T, H, W, B, nc = args.frames, args.height, args.width_px, args.batch, 5
     torch.manual_seed(1234)                                    # identical initial weights on every rank
-    model = mfc.HRNetMultiLarge(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype=args.dtype)
+    cls = mfc.HRNetMultiBasic if args.basic else mfc.HRNetMultiLarge
+    model = cls(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype=args.dtype,
+                optflow_inputs=args.optflow, depth_inputs=args.depth)
     model = model.to(device).train()
     if os.environ.get("MFC_BATCH_WGRAD"):          # tuning: 0 = one launch per weight gradient
         model.batch_wgrad = os.environ["MFC_BATCH_WGRAD"] != "0"
     opt = mfc.FlatAdam(model, lr=1e-4)
-    frames, mask = synth(B, T, H, W, nc, 42 + 2000 + rank, device)
+    frames, mask, depth, flow = synth(B, T, H, W, nc, 42 + 2000 + rank, device, args.depth, args.optflow)
 
     reducer = GradBucketReducer(model, average=False) if world > 1 else None
 
     def step():
         opt.zero_grad()
-        out = model(frames)
+        out = model(frames, optflow=flow, depth=depth)
         loss, _ = mfc.mfc_loss(out, mask, global_batch=True)      # loss over the global batch (all-reduce of 26 sums), as the reference
         loss.backward()                                             # (per-bucket all-reduces start inside, next to the backward kernels)
         if reducer is not None:
@@ -188,7 +199,10 @@ def main():
         dt = float(tt)
     final_loss = float(loss.detach())
 
-    cfg_label = ("BASELINE.json configs[2]" if (T, H, W, B) == (3, 480, 640, 8) else
+    extra = ("+depth" if args.depth else "") + ("+optflow" if args.optflow else "")
+    cfg_label = ("per-GPU share of BASELINE.json configs[3]" if (T, H, W, B, extra) == (3, 480, 640, 4, "+depth+optflow") else
+                 "custom inputs" if extra else
+                 "BASELINE.json configs[2]" if (T, H, W, B) == (3, 480, 640, 8) else
                  "per-GPU share of BASELINE.json configs[4]" if (T, H, W, B, args.width) == (5, 720, 960, 8, 48) else "custom size")
     if rank == 0:
         # dominant kernel = the conv_igemm instantiation (one profiler bucket per <NT, MT, PMAX>, as rocprof names them) with the
@@ -233,7 +247,7 @@ def main():
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"MFCNet T={T} RGB-only (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, fwd+bwd+Adam "
+               "config": {"workload": f"MFCNet{'-Basic' if args.basic else ''} T={T} {'RGB' + extra if extra else 'RGB-only'} (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, fwd+bwd+Adam "
                                       f"({cfg_label})", "width": args.width, "global_batch": world * B,
                           "frames_per_clip": T, "parallelism": f"dp{world}", "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
                "roofline": roof}
