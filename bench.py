@@ -47,7 +47,7 @@ def pmc_traffic(NT, MT, PM, NW, args):
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_w{args.width}_pmc_traffic.json")))      # newest round's passes
     if args.dtype != "bf16" or (args.batch, args.frames, args.height, args.width_px) != (8, 3, 480, 640) or not found \
-            or args.depth or args.optflow or args.basic:
+            or args.depth or args.optflow or args.basic or args.single or args.fwd_only:
         return None, None
     path = found[-1]
     tag = os.path.basename(path)
@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--depth", action="store_true", help="add the T depth maps (BASELINE.json configs[3])")
     ap.add_argument("--optflow", action="store_true", help="add the T-1 optical-flow fields (BASELINE.json configs[3])")
     ap.add_argument("--basic", action="store_true", help="model_type HRNetMulti-Basic (flow warp) instead of HRNetMulti-Large")
+    ap.add_argument("--single", action="store_true", help="single-frame HRNet (model_type 'HRNet'): one [B,3,H,W] tensor in (BASELINE.json configs[1])")
+    ap.add_argument("--fwd-only", action="store_true", help="eval-mode forward only (no loss / backward / optimizer)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
@@ -120,12 +122,18 @@ def main():
     from mfcnet_amd import _lib as L
     from mfcnet_amd.dist import GradBucketReducer
 
+    if args.single:
+        args.frames = 1
     T, H, W, B, nc = args.frames, args.height, args.width_px, args.batch, 5
     torch.manual_seed(1234)                                    # identical initial weights on every rank
     cls = mfc.HRNetMultiBasic if args.basic else mfc.HRNetMultiLarge
-    model = cls(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype=args.dtype,
-                optflow_inputs=args.optflow, depth_inputs=args.depth)
-    model = model.to(device).train()
+    if args.single:
+        model = mfc.HighResolutionNetHIP(num_classes=nc, width=args.width, compute_dtype=args.dtype)
+    else:
+        model = cls(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype=args.dtype,
+                    optflow_inputs=args.optflow, depth_inputs=args.depth)
+    model = model.to(device)
+    model = model.eval() if args.fwd_only else model.train()
     if os.environ.get("MFC_BATCH_WGRAD"):          # tuning: 0 = one launch per weight gradient
         model.batch_wgrad = os.environ["MFC_BATCH_WGRAD"] != "0"
     opt = mfc.FlatAdam(model, lr=1e-4)
@@ -133,9 +141,15 @@ def main():
 
     reducer = GradBucketReducer(model, average=False) if world > 1 else None
 
+    def fwd():
+        return model(frames[0]) if args.single else model(frames, optflow=flow, depth=depth)
+
     def step():
+        if args.fwd_only:
+            with torch.no_grad():
+                return fwd().float().mean()
         opt.zero_grad()
-        out = model(frames, optflow=flow, depth=depth)
+        out = fwd()
         loss, _ = mfc.mfc_loss(out, mask, global_batch=True)      # loss over the global batch (all-reduce of 26 sums), as the reference
         loss.backward()                                             # (per-bucket all-reduces start inside, next to the backward kernels)
         if reducer is not None:
@@ -201,7 +215,8 @@ def main():
 
     extra = ("+depth" if args.depth else "") + ("+optflow" if args.optflow else "")
     cfg_label = ("per-GPU share of BASELINE.json configs[3]" if (T, H, W, B, extra) == (3, 480, 640, 4, "+depth+optflow") else
-                 "custom inputs" if extra else
+                 "BASELINE.json configs[1]" if (args.single, args.fwd_only, H, W, B) == (True, True, 480, 640, 8) else
+                 "custom inputs" if (extra or args.single or args.fwd_only) else
                  "BASELINE.json configs[2]" if (T, H, W, B) == (3, 480, 640, 8) else
                  "per-GPU share of BASELINE.json configs[4]" if (T, H, W, B, args.width) == (5, 720, 960, 8, 48) else "custom size")
     if rank == 0:
@@ -243,11 +258,11 @@ def main():
                     "all_wgrad_tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms else None,
                     "conv_ms_per_step": round(fam_ms / max(prof_steps, 1), 3), "wgrad_ms_per_step": round(wg_ms / max(prof_steps, 1), 3),
                     "profiled_steps": prof_steps, "profiled_step_streams": "serial"}
-        out = {"metric": f"frames/sec ({H}x{W}, T={T}, HRNet MFCNet) fwd+bwd", "value": round(world * B * T * args.steps / dt, 2),
+        out = {"metric": f"frames/sec ({H}x{W}, T={T}, HRNet {'single-frame' if args.single else 'MFCNet'}) {'fwd' if args.fwd_only else 'fwd+bwd'}", "value": round(world * B * T * args.steps / dt, 2),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"MFCNet{'-Basic' if args.basic else ''} T={T} {'RGB' + extra if extra else 'RGB-only'} (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, fwd+bwd+Adam "
+               "config": {"workload": f"{'single-frame HRNet' if args.single else 'MFCNet'}{'-Basic' if args.basic else ''} T={T} {'RGB' + extra if extra else 'RGB-only'} (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, {'eval forward only' if args.fwd_only else 'fwd+bwd+Adam'} "
                                       f"({cfg_label})", "width": args.width, "global_batch": world * B,
                           "frames_per_clip": T, "parallelism": f"dp{world}", "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
                "roofline": roof}

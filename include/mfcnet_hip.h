@@ -181,6 +181,10 @@ typedef struct {
     float eps, momentum;
 } mfc_bnfin_desc;
 int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream);
+/* the same for a DEVICE-resident table of n descriptors in one launch (max_Cp = largest Cp in the table).  The rows must not
+ * depend on each other or on work still in flight; the plan uses it for eval-mode BatchNorms (coefficients from the running
+ * statistics, hrnet.py:31 in `.eval()`), whose ~300 one-block launches otherwise sit on the forward critical path. */
+int mfc_bn_finalize_batch(const mfc_bnfin_desc* table_dev, int32_t n, int32_t max_Cp, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Tensor views used by the element-wise kernels.
@@ -344,7 +348,8 @@ typedef enum {
     MFC_OP_BNBWD_FIN = 6, MFC_OP_BNBWD_APPLY = 7, MFC_OP_MASK_ADD = 8, MFC_OP_HEAD_FWD = 9, MFC_OP_HEAD_BWD = 10,
     MFC_OP_BIAS_GRAD = 11, MFC_OP_MEMSET = 12, MFC_OP_PACK = 13, MFC_OP_UNPACK = 14, MFC_OP_NCHW2NHWC = 15,
     MFC_OP_NHWC2NCHW = 16,
-    MFC_OP_WGRAD_BATCH = 17      /* raw.a = HOST pointer to an mfc_wgrad_desc array (kept alive by the caller), raw.i[0] = n */
+    MFC_OP_WGRAD_BATCH = 17,     /* raw.a = HOST pointer to an mfc_wgrad_desc array (kept alive by the caller), raw.i[0] = n */
+    MFC_OP_BNFIN_BATCH = 18      /* raw.a = DEVICE pointer to an mfc_bnfin_desc array, raw.i[0] = n, raw.i[1] = max Cp */
 } mfc_op_kind;
 
 #define MFC_LANE_ASYNC 0x100

@@ -24,11 +24,10 @@ __device__ inline double replica_sum(const float* base, size_t stride) {
 }
 
 // block = 64 channels x 4 group slots; grid = ceil(Cp / 64)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(mfc_bnfin_desc d) {
-    __shared__ float sm[8][64], sv[8][64];
+__device__ inline void bn_finalize_body(const mfc_bnfin_desc& d, int bxi, float (*sm)[64], float (*sv)[64]) {
     const size_t rstride = (size_t)d.G * 2 * d.Cp;
     const int cl = threadIdx.x & 63, gs = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int c = bxi * 64 + cl;
     if (c < d.Cp) {
         const bool real = c < d.C;
         const float gamma = real ? d.gamma[c] : 0.f, beta = real ? d.beta[c] : 0.f;
@@ -65,7 +64,19 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(mfc_bnfin_desc d) {
         }
         d.running_mean[c] = rm; d.running_var[c] = rv;
     }
-    if (d.num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *d.num_batches_tracked += d.G;
+    if (d.num_batches_tracked && bxi == 0 && threadIdx.x == 0) *d.num_batches_tracked += d.G;
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(mfc_bnfin_desc d) {
+    __shared__ float sm[8][64], sv[8][64];
+    bn_finalize_body(d, blockIdx.x, sm, sv);
+}
+// one launch for a TABLE of finalizes (blockIdx.y = table row): the eval-mode records of a program depend on nothing but the
+// running statistics, so the plan hoists all of them in front of the first convolution
+__global__ __launch_bounds__(256) void bn_finalize_batch_kernel(const mfc_bnfin_desc* tab) {
+    __shared__ float sm[8][64], sv[8][64];
+    const mfc_bnfin_desc d = tab[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= d.Cp) return;
+    bn_finalize_body(d, blockIdx.x, sm, sv);
 }
 
 extern "C" int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream) {
@@ -74,6 +85,14 @@ extern "C" int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream) {
     if (d->C <= 0 || d->C > d->Cp || d->G <= 0) return MFC_ERR_INVALID_ARG;
     if (d->G > 8) return MFC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->Cp + 63) / 64), dim3(256), 0, (hipStream_t)stream, *d);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+extern "C" int mfc_bn_finalize_batch(const mfc_bnfin_desc* table_dev, int32_t n, int32_t max_Cp, void* stream) {
+    if (!table_dev || n <= 0 || max_Cp <= 0) return MFC_ERR_INVALID_ARG;
+    if (n > 65535) return MFC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3((max_Cp + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, table_dev);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

@@ -248,6 +248,7 @@ static int run_one(const mfc_op& o, void* stream) {
         case MFC_OP_WGRAD: return mfc_conv2d_wgrad(&o.u.wgrad, stream);
         case MFC_OP_WGRAD_BATCH: return mfc_conv2d_wgrad_batch((const mfc_wgrad_desc*)o.u.raw.a, o.u.raw.i[0], stream);
         case MFC_OP_BNFIN: return mfc_bn_finalize(&o.u.bnfin, stream);
+        case MFC_OP_BNFIN_BATCH: return mfc_bn_finalize_batch((const mfc_bnfin_desc*)o.u.raw.a, o.u.raw.i[0], o.u.raw.i[1], stream);
         case MFC_OP_COMBINE: return mfc_combine_fwd(&o.u.combine, stream);
         case MFC_OP_BNBWD_REDUCE: return mfc_bnbwd_reduce(&o.u.bnbwd, stream);
         case MFC_OP_BNBWD_FIN: return mfc_bnbwd_finalize(&o.u.bnbwdfin, stream);

@@ -24,6 +24,7 @@ OP_CONV, OP_WGRAD, OP_BNFIN, OP_COMBINE, OP_BNBWD_REDUCE, OP_BNBWD_FIN, OP_BNBWD
 LANE_ASYNC = 0x100
 OP_HEAD_FWD, OP_HEAD_BWD, OP_BIAS_GRAD, OP_MEMSET, OP_PACK, OP_UNPACK, OP_NCHW2NHWC, OP_NHWC2NCHW = range(9, 17)
 OP_WGRAD_BATCH = 17
+OP_BNFIN_BATCH = 18
 WGRAD_MAXBATCH = 8
 
 i32, u64, f32, vp = C.c_int32, C.c_uint64, C.c_float, C.c_void_p
@@ -130,7 +131,7 @@ class Op(C.Structure):
 
 # every symbol include/mfcnet_hip.h declares
 EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_conv2d_wgrad_parts", "mfc_conv2d_wgrad_batch", "mfc_unpack_wgrad",
-           "mfc_bn_finalize", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
+           "mfc_bn_finalize", "mfc_bn_finalize_batch", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd", "mfc_confusion_counts", "mfc_adam_step", "mfc_program_run", "mfc_program_profile", "mfc_graph_capture", "mfc_graph_launch", "mfc_graph_destroy",
            "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect"]
@@ -169,6 +170,7 @@ def _load():
                  "mfc_bnbwd_apply", "mfc_bnbwd_finalize", "mfc_mask_add", "mfc_head_gather_fwd", "mfc_loss_fwd",
                  "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd"):
         getattr(lib, name).argtypes = [vp, vp]
+    lib.mfc_bn_finalize_batch.argtypes = [vp, i32, i32, vp]
     lib.mfc_conv2d_lds_bytes.argtypes = [vp]
     lib.mfc_conv2d_wgrad_parts.argtypes = [vp]
     lib.mfc_conv2d_wgrad_batch.argtypes = [vp, i32, vp]

@@ -687,6 +687,17 @@ class Plan:
         r = L.RawOp(self._pack_dev.data_ptr(), 0, 0, 0)
         r.i[0:3] = [npk, nbk, self.dtype]
         pro.append((L.OP_PACK, r))
+        # eval-mode BatchNorm finalizes read only the running statistics: one table launch in front of the first convolution
+        # instead of one one-block launch between every conv and its consumer
+        ev = [rec for rec in self.fwd if rec[0] == L.OP_BNFIN and not rec[1].training]
+        if len(ev) > 1 and getattr(self.m, "batch_eval_bnfin", True):
+            tab = (L.BnFinDesc * len(ev))(*[rec[1] for rec in ev])
+            self._bnfin_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+            r = L.RawOp(self._bnfin_dev.data_ptr(), 0, 0, 0)
+            r.i[0:2] = [len(ev), max(rec[1].Cp for rec in ev)]
+            pro.append((L.OP_BNFIN_BATCH, r))
+            keep = set(id(rec) for rec in ev)
+            self.fwd[:] = [rec for rec in self.fwd if id(rec) not in keep]
         self.n_fwd_ops = len(self.fwd) + len(pro)
         self.fwd_prog = self._program(pro + self.fwd)
         if self.need_backward:

@@ -61,6 +61,7 @@ def test_descriptors_are_validated_before_any_launch(L):
     assert L.lib.mfc_conv2d_fwd(C.byref(L.ConvDesc()), None) == -1
     assert L.lib.mfc_conv2d_wgrad(C.byref(L.WgradDesc()), None) == -1
     assert L.lib.mfc_bn_finalize(C.byref(L.BnFinDesc()), None) == -1
+    assert L.lib.mfc_bn_finalize_batch(None, 3, 64, None) == -1
     assert L.lib.mfc_combine_fwd(C.byref(L.CombineDesc()), None) == -1
     assert L.lib.mfc_program_run(None, 3, None) == -1
     d = L.ConvDesc(16, 16, 16, 0, 0, 0, L.BF16, 2, 8, 8, 12, 12, 8, 8, 16, 16, 8, 8, 3, 3, -1, -1, 1, 1, 1, 0, 0, 0, 2, 0, 0, 0)

@@ -274,6 +274,29 @@ def test_lanes_do_not_change_results(mfc):
     assert rel_l2(g1.numpy(), g0.numpy()) < GRAD_RTOL      # (the order of the BN statistic atomics is the only freedom; see the noise floor above)
 
 
+def test_hoisted_eval_bn_finalize_is_bit_identical(mfc):
+    """Eval-mode BatchNorm finalizes run as ONE table launch in front of the program (mfc_bn_finalize_batch); the logits are
+    those of the per-record form -- bit for bit in full eval mode; with only the base model frozen (engine.py:25-26) up to
+    the last-bit noise of the head's training-mode statistic atomics."""
+    for name, mode in (("large_rgb_eval", "eval"), ("large_flow_headonly", "headonly")):
+        cfg, z = load_case(name)
+        frames, flows, depths, mask = case_inputs(cfg)
+        outs = []
+        for hoist in (True, False):
+            m = build(mfc, cfg)
+            m.batch_eval_bnfin = hoist
+            set_mode(m, mode)
+            with torch.no_grad():
+                outs.append(m(dev(frames), optflow=dev(flows), depth=dev(depths)).cpu())
+            kinds = [op.kind for op in next(iter(m._plans.values())).fwd_prog]
+            from mfcnet_amd import _lib as L
+            assert (L.OP_BNFIN_BATCH in kinds) == hoist
+        if mode == "eval":
+            assert torch.equal(outs[0], outs[1]), name
+        else:                                   # (the head's training-mode statistic atomics are unordered: last-bit noise)
+            assert float((outs[0] - outs[1]).abs().max()) <= ATOL, name
+
+
 def test_captured_graph_replays_the_forward_program(mfc):
     """mfc_graph_capture / mfc_graph_launch: the forward program as a hipGraph (lanes become graph branches) writes the
     same logits as mfc_program_run."""

@@ -18,7 +18,7 @@ import mfcnet_amd as mfc  # noqa: E402
 from mfcnet_amd import _lib as L  # noqa: E402
 
 KIND = {1: "conv", 2: "wgrad", 3: "bnfin", 4: "combine", 5: "bnbwd_reduce", 6: "bnbwd_fin", 7: "bnbwd_apply", 8: "mask_add",
-        9: "head_fwd", 10: "head_bwd", 11: "bias_grad", 12: "memset", 13: "pack", 14: "unpack", 15: "nchw2nhwc", 16: "nhwc2nchw"}
+        9: "head_fwd", 10: "head_bwd", 11: "bias_grad", 12: "memset", 13: "pack", 14: "unpack", 15: "nchw2nhwc", 16: "nhwc2nchw", 17: "wgrad_batch", 18: "bnfin_batch"}
 
 
 def describe(o, esz):
