@@ -166,6 +166,8 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_WGRAD_MAXPX"):           # (before the plan is built, like MFC_WGRAD_BLOCKS)
+        L.lib.mfc_set_flag(21, int(os.environ["MFC_WGRAD_MAXPX"]))
     if os.environ.get("MFC_CONV_NW8"):              # weight (%) of the 8-wave conv geometries in the search (0 = never); before the plan is built
         L.lib.mfc_set_flag(19, int(os.environ["MFC_CONV_NW8"]))
     if os.environ.get("MFC_CONV_FILL_PCT"):         # before the plan is built (the packed weight layouts depend on the geometry)

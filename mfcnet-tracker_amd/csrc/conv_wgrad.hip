@@ -23,6 +23,7 @@ static int g_wgrad_ablate = 0;
 static int g_wgrad_deep = 0;          // prefetch-distance-2 wave kernel when a launch has at most one workgroup per CU.  Alone it is 15 % faster
                                      // (35.7 -> 30.2 us), but its 308 VGPRs cannot share a SIMD with a conv wave (246), so next to the
                                      // critical chain the step gets SLOWER (546 -> 530 frames/s): off by default; mfc_set_flag(17, v)
+static int g_wgrad_maxpx = 6000;     // output pixels one workgroup may walk before the pixel axis is split beyond g_wgrad_blocks (0 = never); mfc_set_flag(21, n)
 static int g_wgrad_blocks = 256;     // target workgroups per wave-kernel launch (S = blocks / Y).  Alone, 512 (2 per CU) is fastest; in the
                                      // step the launches run on the detached stream next to the critical chain, and 1 per CU leaves that
                                      // chain half of every CU (measured 541 vs 529 frames/s); tuning: mfc_set_flag(11, n)
@@ -58,6 +59,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 18) return mfc_conv_set_fill_pct(value);
     if (id == 19) return mfc_conv_set_nw8(value);
     if (id == 20) { g_conv_wres = value; return 0; }
+    if (id == 21) { g_wgrad_maxpx = value; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
@@ -1012,7 +1014,17 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only, 
     int S = d->splits;
     const int nb = d->batch > 1 ? d->batch : 1;      // problems sharing the launch: each gets 1/nb of the workgroups
     if (nb > MFC_WGRAD_MAXBATCH || (batch && nbatch != nb)) return MFC_ERR_INVALID_ARG;
-    if (S <= 0) S = ceil_div(g_wgrad_blocks, Y * nb);
+    if (S <= 0) {
+        S = ceil_div(g_wgrad_blocks, Y * nb);
+        // few output tiles over a huge pixel count (temporal head at full resolution, stem): one workgroup per CU would walk tens of
+        // thousands of pixels with 1-9 MFMAs per staged strip; split the pixel axis further (up to 8 workgroups per CU)
+        if (g_wgrad_maxpx > 0) {
+            long s2 = ((long)f.N * f.Hout * f.Wout + g_wgrad_maxpx - 1) / g_wgrad_maxpx;
+            const long cap = ceil_div(2048, Y * nb);
+            if (s2 > cap) s2 = cap;
+            if (s2 > S) S = (int)s2;
+        }
+    }
     if (S * 4 > f.ntiles) S = ceil_div(f.ntiles, 4);
     if (S < 1) S = 1;
     f.splits = S;

@@ -8,7 +8,7 @@ import mfcnet_amd as mfc
 from mfcnet_amd import _lib as L
 lib = L.lib
 width = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-B, T, H, W = 8, 3, 480, 640
+B, T, H, W = (int(sys.argv[2]) if len(sys.argv) > 2 else 8), 3, 480, 640
 dev = torch.device("cuda")
 model = mfc.HRNetMultiLarge(num_classes=5, num_frames=T, pretrained=False, width=width, compute_dtype="bf16").to(dev).train()
 frames = [torch.randn(B, 3, H, W, device=dev) for _ in range(T)]
