@@ -118,6 +118,12 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if os.environ.get("MFC_DUMMY_STREAMS"):         # experiment: streams created (and used) by others before ours shift the HW-queue mapping
+        _dummies = [torch.cuda.Stream() for _ in range(int(os.environ["MFC_DUMMY_STREAMS"]))]
+        for ds in _dummies:
+            with torch.cuda.stream(ds):
+                torch.zeros(16, device=device).add_(1)
+        torch.cuda.synchronize()
     import mfcnet_amd as mfc
     from mfcnet_amd import _lib as L
     from mfcnet_amd.dist import GradBucketReducer
@@ -166,6 +172,8 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_PROBE_STREAMS"):
+        L.lib.mfc_set_flag(22, int(os.environ["MFC_PROBE_STREAMS"]))
     if os.environ.get("MFC_WGRAD_MAXPX"):           # (before the plan is built, like MFC_WGRAD_BLOCKS)
         L.lib.mfc_set_flag(21, int(os.environ["MFC_WGRAD_MAXPX"]))
     if os.environ.get("MFC_CONV_NW8"):              # weight (%) of the 8-wave conv geometries in the search (0 = never); before the plan is built

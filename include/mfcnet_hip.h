@@ -410,7 +410,8 @@ int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded eve
  *  16  detached stream priority (0; read at stream creation)              17  wgrad: prefetch-distance-2 variant (0)
  *  18  conv: exponent (%) of the under-filled-launch penalty (100)         19  conv: score weight (%) of the 8-wave geometries (90)
  *  20  conv: single-stage launches keep every cout block's weights in LDS and stage each pixel tile once (1)
- *  21  wgrad: output pixels per workgroup above which the pixel axis is split further than switch 11 asks (6000; 0 = never) */
+ *  21  wgrad: output pixels per workgroup above which the pixel axis is split further than switch 11 asks (6000; 0 = never)
+ *  22  lanes: measure which side streams really overlap with the caller's stream before choosing them (1; see runtime.hip) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

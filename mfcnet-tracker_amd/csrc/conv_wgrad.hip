@@ -30,6 +30,7 @@ static int g_wgrad_blocks = 256;     // target workgroups per wave-kernel launch
 int mfc_conv_set_lds_kb(int v);
 int mfc_conv_set_ybfast(int v);
 int mfc_set_lanes(int on);
+int mfc_set_probe_streams(int v);
 int mfc_set_async_streams(int n);
 int mfc_set_lane_streams(int n);
 int mfc_set_async_on_lane(int k);
@@ -60,6 +61,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 19) return mfc_conv_set_nw8(value);
     if (id == 20) { g_conv_wres = value; return 0; }
     if (id == 21) { g_wgrad_maxpx = value; return 0; }
+    if (id == 22) return mfc_set_probe_streams(value);
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }

@@ -318,7 +318,36 @@ int mfc_set_async_on_lane(int k) { g_async_on_lane = k; return 0; }
 int mfc_set_own_main(int v) { g_own_main = v; return 0; }
 int mfc_set_async_streams(int n) { g_async_n = n < 1 ? 1 : (n > MFC_ASYNC_STREAMS ? MFC_ASYNC_STREAMS : n); return 0; }
 
-static LaneSet* lanes_for_device() {
+// ---- which of our streams really run next to each other? ----
+// HIP folds streams onto GPU_MAX_HW_QUEUES (4) hardware queues in creation order, counting every stream the process ever made
+// (torch's pool, RCCL's).  Two streams that land on one hardware queue execute in order, so a detached stream that shares
+// the queue of the main chain (or of the side lane) silently loses the overlap: measured 43.5 -> 48.7 / 52.2 ms per step,
+// depending only on how many streams existed before ours.  So the interpreter does not trust creation order: it makes a few
+// candidates and MEASURES which ones overlap with the caller's stream (a 150 us spin on one, an empty kernel on the other).
+__global__ void mfc_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    for (int guard = 0; guard < 8192 && wall_clock64() - t0 < ticks; ++guard) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void mfc_empty_kernel() {}
+static int g_probe_streams = 1;      // mfc_set_flag(22, v)
+int mfc_set_probe_streams(int v) { g_probe_streams = v; return 0; }
+static bool streams_overlap(hipStream_t a, hipStream_t b) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) { if (ea) (void)hipEventDestroy(ea); return true; }
+    hipLaunchKernelGGL(mfc_spin_kernel, dim3(1), dim3(64), 0, a, (long long)15000);      // wall_clock64 ticks at 100 MHz
+    (void)hipEventRecord(ea, a);
+    hipLaunchKernelGGL(mfc_empty_kernel, dim3(1), dim3(64), 0, b);
+    (void)hipEventRecord(eb, b);
+    bool over = true;
+    float ms = 0.f;
+    if (hipEventSynchronize(ea) == hipSuccess && hipEventSynchronize(eb) == hipSuccess && hipEventElapsedTime(&ms, eb, ea) == hipSuccess)
+        over = ms > 0.03f;           // the empty kernel finished well before the spin did
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    (void)hipGetLastError();
+    return over;
+}
+
+static LaneSet* lanes_for_device(hipStream_t caller = nullptr, bool may_probe = false) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     LaneSet* L = &g_lanes[dev];
@@ -345,6 +374,22 @@ static LaneSet* lanes_for_device() {
             if (hipEventCreateWithFlags(&L->ajoin[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         for (int i = 0; i < MFC_ASYNC_EVENTS; ++i)
             if (hipEventCreateWithFlags(&L->aev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (may_probe && g_probe_streams && g_async_prio == 0) {
+            // candidates: every side stream made above.  s[2] <- the first one that overlaps with the caller's stream,
+            // as[0] <- the first other one that overlaps with the caller's stream AND with s[2]
+            hipStream_t* cand[MFC_MAX_LANES - 1 + MFC_ASYNC_STREAMS]; int nc = 0;
+            for (int i = 2; i <= MFC_MAX_LANES; ++i) cand[nc++] = &L->s[i];
+            for (int i = 0; i < MFC_ASYNC_STREAMS; ++i) cand[nc++] = &L->as[i];
+            static const bool dbg = getenv("MFC_DEBUG") != nullptr;
+            int pick_l = -1, pick_a = -1;
+            for (int i = 0; i < nc && pick_l < 0; ++i)
+                if (streams_overlap(caller, *cand[i])) pick_l = i;
+            for (int i = 0; i < nc && pick_l >= 0 && pick_a < 0; ++i)
+                if (i != pick_l && streams_overlap(caller, *cand[i]) && streams_overlap(*cand[pick_l], *cand[i])) pick_a = i;
+            if (dbg) fprintf(stderr, "[mfc lanes] stream probe: side lane <- candidate %d, detached <- candidate %d (of %d)\n", pick_l, pick_a, nc);
+            if (pick_l >= 0) { hipStream_t t = L->s[2]; L->s[2] = *cand[pick_l]; *cand[pick_l] = t; if (pick_a == 0) pick_a = pick_l; }
+            if (pick_a >= 0) { hipStream_t t = L->as[0]; L->as[0] = *cand[pick_a]; *cand[pick_a] = t; }
+        }
         L->ready = true;
     }
     return L;
@@ -363,7 +408,7 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
     bool multi = false;
     if (g_lanes_on)
         for (int i = 0; i < n && !multi; ++i) multi = ops[i].lane != 0;
-    if (multi && !(L = lanes_for_device())) return MFC_ERR_LAUNCH;
+    if (multi && !(L = lanes_for_device(caller, !g_capturing))) return MFC_ERR_LAUNCH;
     // with lanes the whole program runs on the interpreter's own streams, ordered after / before the caller's stream by events
     hipStream_t mainst = (multi && !g_capturing && g_own_main) ? L->m : caller;
     if (mainst != caller) { (void)hipEventRecord(L->enter, caller); (void)hipStreamWaitEvent(mainst, L->enter, 0); }
@@ -424,7 +469,7 @@ extern "C" int mfc_graph_capture(const mfc_op* ops, int32_t n, void* stream, voi
     if (!ops || n <= 0 || !stream || !exec_out) return MFC_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (g_mfc_prof_on) return MFC_ERR_UNSUPPORTED;
-    if (!lanes_for_device()) return MFC_ERR_LAUNCH;                  // create side streams / events outside the capture
+    if (!lanes_for_device(st, true)) return MFC_ERR_LAUNCH;          // create (and probe) side streams / events outside the capture
     if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) return MFC_ERR_LAUNCH;
     g_capturing = true;
     const int rc = mfc_program_run(ops, n, stream);
