@@ -114,7 +114,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            # RCCL's stream from the high-priority pool: those streams have hardware queues of their own, so the bucket
+            # all-reduces can never land on the hardware queue of the backward chain ("which streams?")
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+            except Exception:
+                opts = None
+            dist.init_process_group("nccl", device_id=device, pg_options=opts)
         else:
             dist.init_process_group(args.backend)
 
