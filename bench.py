@@ -180,6 +180,8 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_CONV_GEMM"):
+        L.lib.mfc_set_flag(23, int(os.environ["MFC_CONV_GEMM"]))
     if os.environ.get("MFC_PROBE_STREAMS"):
         L.lib.mfc_set_flag(22, int(os.environ["MFC_PROBE_STREAMS"]))
     if os.environ.get("MFC_WGRAD_MAXPX"):           # (before the plan is built, like MFC_WGRAD_BLOCKS)
@@ -242,7 +244,7 @@ def main():
         # largest total time in the profiled step; bucket layout: include/mfcnet_hip.h (mfc_prof_result)
         dt_base = 64 if args.dtype == "bf16" else 0
         roof = None
-        conv = [(dt_base + s, s) for s in range(40)]
+        conv = [(dt_base + s, s) for s in range(41)]          # 40 = conv_gemm1x1_kernel (big 1x1 convolutions)
         live = [(b, s) for b, s in conv if prof.launches[b]]
         if live:
             best, bslot = max(live, key=lambda bs: prof.ms[bs[0]])
@@ -250,10 +252,14 @@ def main():
             avg_ms = prof.ms[best] / n
             achieved = prof.flops[best] / n / (avg_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.dtype]
-            NW = 8 if bslot >= 20 else 4
-            NT = NT_SLOTS[(bslot % 20) // 4]
-            MT, PM = [(4, 3), (4, 6), (2, 4), (2, 10)][bslot % 4]
-            kname = f"conv_igemm_kernel<{'__bf16' if args.dtype == 'bf16' else 'float'}, {NT}, {MT}, {PM}, {NW}>"
+            if bslot == 40:
+                NT, MT, PM, NW = 4, 8, 0, 8
+                kname = "conv_gemm1x1_kernel"
+            else:
+                NW = 8 if bslot >= 20 else 4
+                NT = NT_SLOTS[(bslot % 20) // 4]
+                MT, PM = [(4, 3), (4, 6), (2, 4), (2, 10)][bslot % 4]
+                kname = f"conv_igemm_kernel<{'__bf16' if args.dtype == 'bf16' else 'float'}, {NT}, {MT}, {PM}, {NW}>"
             fam_ms = sum(prof.ms[b] for b, _ in conv)
             fam_fl = sum(prof.flops[b] for b, _ in conv)
             wgb = [128 + dt_base + s for s in range(64)]

@@ -69,6 +69,9 @@ typedef enum {
  *   dgrad of stride 1   :  flipped taps (done by the weight packer), dh0=-(k-1-p)
  *   dgrad of stride 2   :  four launches, one per output parity class
  * Wp is the packed weight image produced by mfc_pack_weights.
+ * bf16 1x1 / stride-1 launches without input transform, with >= 128 input and output channels and a pixel count that is a
+ * multiple of 256 (last_layer[0], hrnet.py:334-351, and its data gradient) run as a plain GEMM with 256x256 tiles
+ * (conv_gemm1x1.hip); mfc_conv2d_layout reports the weight blocking of whichever kernel will run.
  * Optional epilogue: + bias[co]; out = acc + out (accumulate); per-(group,channel)
  * sum / sum-of-squares of the fp32 results added to out_stats[replica][G][2][Cs].
  * ------------------------------------------------------------------------------------ */
@@ -392,7 +395,7 @@ int mfc_program_profile(const mfc_op* ops, int32_t n, int32_t reps, float* ms_ou
  * bucket = family*128 + dtype*64 + slot (dtype 0 = fp32, 1 = bf16);
  *   family 0 = conv_igemm_kernel<T, NT, MT, PMAX>: slot = ntIndex*4 + variant, NT in {1,2,3,4,6} -> ntIndex 0..4,
  *              variant 0..3 = <MT,PMAX> in {<4,3>, <4,6>, <2,4>, <2,10>}, +20 for the 8-wave instantiations (NW = 8)
- *              (one bucket per kernel instantiation, as rocprof sees it)
+ *              (one bucket per kernel instantiation, as rocprof sees it); slot 40 = conv_gemm1x1_kernel (big 1x1 convolutions, bf16)
  *   family 1 = weight gradient: slot 0..2 generic kernel (TPW 8/16/28), 8..10 fast kernel (TB 1/3/11), 16..17 wave kernel (TB 3/11) */
 #define MFC_PROF_BUCKETS 256
 typedef struct { double ms[MFC_PROF_BUCKETS]; double flops[MFC_PROF_BUCKETS]; double bytes[MFC_PROF_BUCKETS]; int64_t launches[MFC_PROF_BUCKETS]; } mfc_prof_result;
@@ -411,7 +414,9 @@ int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded eve
  *  18  conv: exponent (%) of the under-filled-launch penalty (100)         19  conv: score weight (%) of the 8-wave geometries (90)
  *  20  conv: single-stage launches keep every cout block's weights in LDS and stage each pixel tile once (1)
  *  21  wgrad: output pixels per workgroup above which the pixel axis is split further than switch 11 asks (6000; 0 = never)
- *  22  lanes: measure which side streams really overlap with the caller's stream before choosing them (1; see runtime.hip) */
+ *  22  lanes: measure which side streams really overlap with the caller's stream before choosing them (1; see runtime.hip)
+ *  23  conv: big 1x1 / stride-1 convolutions without input transform run as a plain GEMM (conv_gemm1x1.hip) (1)
+ *  24  conv: smallest Cin and Cout sent to that GEMM (128) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

@@ -1,0 +1,284 @@
+// libmfcnet_hip: the big 1x1 convolutions as a plain GEMM (bf16, gfx950).
+//
+// hrnet.py:334-351 `last_layer[0]` (480 -> 480 channels for W32, 720 -> 720 for W48, at 120x160 with all T*B images) and its
+// data gradient are 212 / 478 GFLOP each and sit after the last join of the branch lanes, i.e. on the critical chain of the step.
+// In the general kernel (conv_igemm.hip) a wave owns 32 pixels x 96 channels and the input tile goes through registers in
+// 64-channel chunks: 12 MFMAs per 8 LDS fragment reads (LDS-bandwidth bound, ~220-280 TFLOP/s) and the input is re-read once per
+// 96-channel block.  A 1x1 / stride-1 convolution has no halo, so here it runs as Y[M][Cout] = X[M][Cin] . W^T:
+//   * workgroup = 8 waves, tile 256 pixels x 256 output channels, K chunks of 64 channels; wave (wm, wn) owns 128 pixels x 64
+//     channels = 8 x 4 MFMA tiles (v_mfma_f32_16x16x32_bf16): 32 MFMAs per 12 fragment reads;
+//   * both operands go global -> LDS by DMA (global_load_lds_dwordx4), double buffered, no registers in the staging path: the
+//     weights are the packed image of mfc_pack_weights ([chunk][cout block][granule][256 couts], one 32 KiB stage = one LDS
+//     image), the activations land as [pixel][granule ^ (pixel & 7)] (XOR swizzle: the DMA writes lane-contiguous LDS, so the
+//     swizzle is applied to the SOURCE granule each lane fetches -- free), which makes the fragment reads conflict free;
+//   * persistent workgroups over contiguous pixel-tile ranges; the input is read once per 256-channel block;
+//   * epilogue as in conv_igemm: + bias, per-(group, channel) sum / sum of squares, bf16 rows transposed across the four 16-lane
+//     groups (v_permlane32_swap / v_permlane16_swap) so that every lane stores 16 contiguous bytes.
+// Dispatched from mfc_conv2d_fwd / mfc_conv2d_layout (conv_igemm.hip) when gemm1x1_eligible(); everything else, and the
+// fp32 parity mode, keeps the general kernel.
+#include "common.h"
+
+struct GemmK {
+    const char* in; const char* wp; char* out; const float* bias; float* out_stats;
+    int M, Cin_p, Cin_g, Cout_p, Cout;
+    int nchunks, Yblocks, ntiles, tiles_per_block;
+    int px_per_group, G, accumulate;
+};
+
+template <int CTRL> __device__ inline float g_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ inline float g_row16_sum(float v) {      // sum over the 16 lanes of a DPP row (result in every lane)
+    v = g_dpp_add<0xB1>(v); v = g_dpp_add<0x4E>(v); v = g_dpp_add<0x141>(v); v = g_dpp_add<0x140>(v);
+    return v;
+}
+
+constexpr int G_BM = 256, G_BN = 256, G_KG = 8;                 // pixels, couts, granules (of 8 channels) per stage
+constexpr int G_ABYTES = G_BM * G_KG * 16, G_BBYTES = G_KG * G_BN * 16;      // 32 KiB each
+constexpr int G_OFF_A0 = 0, G_OFF_A1 = G_ABYTES, G_OFF_B0 = 2 * G_ABYTES, G_OFF_B1 = 2 * G_ABYTES + G_BBYTES;
+constexpr int G_OFF_RED = 2 * G_ABYTES + 2 * G_BBYTES;        // float [8 waves][2][64]
+constexpr int G_LDS = G_OFF_RED + 8 * 2 * 64 * 4;
+
+__global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)(smem + G_OFF_RED);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int t0 = Lb * p.tiles_per_block;
+    const int ntl = min(p.tiles_per_block, p.ntiles - t0);
+    if (ntl <= 0) return;
+    const bool ybfast = (p.out_stats == nullptr);           // with statistics: cout block slowest, so that the sums stay in LDS over many tiles
+    const int nunits = ntl * p.Yblocks;
+    const int S = nunits * p.nchunks;
+    const int cq = (lane >> 4) * 4;
+
+    auto unit_of = [&](int u, int& t, int& yb) {
+        if (ybfast) { t = t0 + u / p.Yblocks; yb = u - (u / p.Yblocks) * p.Yblocks; }
+        else { yb = u / ntl; t = t0 + (u - yb * ntl); }
+    };
+    // DMA of stage (tile t, chunk c, cout block yb) into buffer `par`
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma1k = [&](const char* g, unsigned ldst) {
+        unsigned keep;
+        ldst = __builtin_amdgcn_readfirstlane(ldst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
+    };
+    auto dma_stage = [&](int t, int c, int yb, int par) {
+        const unsigned la = lds0 + (par ? G_OFF_A1 : G_OFF_A0), lb = lds0 + (par ? G_OFF_B1 : G_OFF_B0);
+        const char* wsrc = p.wp + (size_t)(c * p.Yblocks + yb) * G_BBYTES + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = wave * 4 + i;                     // 1-KiB piece: pixels q*8 .. q*8+7, all 8 granule slots
+            const int pl = q * 8 + (lane >> 3);
+            const int gi = min(c * G_KG + ((lane & 7) ^ (pl & 7)), p.Cin_g - 1);      // (tail chunk: a valid granule; its weights are zero)
+            dma1k(p.in + ((size_t)t * G_BM + pl) * p.Cin_p * 2 + (size_t)gi * 16, la + q * 1024);
+            dma1k(wsrc + q * 1024, lb + q * 1024);
+        }
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragment addressing: A (pixels) [pl][slot ^ (pl & 7)], pl = wm*128 + mt*16 + (lane & 15); B (couts) [slot][256 couts]
+    const int a_row = (wm * 128 + (lane & 15)) * 128;
+    const int a_k0 = (((lane >> 4)) ^ (lane & 7)) * 16, a_k1 = ((4 + (lane >> 4)) ^ (lane & 7)) * 16;
+    const int b_off = ((lane >> 4) * G_BN + wn * 64 + (lane & 15)) * 16;
+
+    for (int i = tid; i < 8 * 2 * 64; i += 512) red[i] = 0.f;
+    int t, yb;
+    unit_of(0, t, yb);
+    dma_stage(t, 0, yb, 0);
+    dma_wait();
+    __syncthreads();
+
+    int u = 0, c = 0;
+    int red_grp = -1, red_yb = -1; bool red_live = false;
+    auto stats_flush = [&]() {          // every wave has added its row sums to red[wave]; sum the two pixel halves, publish, clear
+        __syncthreads();
+        if (tid < 512) {
+            const int which = tid >> 8, cl = tid & 255;
+            const int w0 = (cl >> 6) * 2, ch = cl & 63;
+            const float s = red[(w0 * 2 + which) * 64 + ch] + red[((w0 + 1) * 2 + which) * 64 + ch];
+            const int co = red_yb * G_BN + cl;
+            if (co < p.Cout_p) atomicAdd(p.out_stats + (((size_t)(Lb % MFC_R) * p.G + red_grp) * 2 + which) * p.Cout_p + co, s);
+        }
+        __syncthreads();
+        for (int i = tid; i < 8 * 2 * 64; i += 512) red[i] = 0.f;
+        __syncthreads();
+        red_live = false;
+    };
+
+    for (int s = 0; s < S; ++s) {
+        // next stage coordinates
+        int u2 = u, c2 = c + 1, t2 = t, yb2 = yb;
+        if (c2 == p.nchunks) { c2 = 0; ++u2; if (u2 < nunits) unit_of(u2, t2, yb2); }
+        if (s + 1 < S) dma_stage(t2, c2, yb2, (s + 1) & 1);
+
+        // ---------------- compute: 2 k-steps of 32 channels ----------------
+        const char* A = smem + ((s & 1) ? G_OFF_A1 : G_OFF_A0) + a_row;
+        const char* B = smem + ((s & 1) ? G_OFF_B1 : G_OFF_B0) + b_off;
+        const int n0 = yb * G_BN + wn * 64;
+        const int ntv = min(4, (p.Cout - n0 + 15) >> 4);         // cout tiles of this wave that hold real channels (wave-uniform)
+        if (ntv > 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 x[8], w[4];
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) x[mt] = *(const bf16x8*)(A + mt * 16 * 128 + (ks ? a_k1 : a_k0));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) w[nt] = *(const bf16x8*)(B + ks * 4 * G_BN * 16 + nt * 256);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    if (nt < ntv) {
+#pragma unroll
+                        for (int mt = 0; mt < 8; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], x[mt], acc[mt][nt], 0, 0, 0);
+                    }
+            }
+        }
+        // the DMA of the next stage has landed (this wave's pieces), then everybody's; the other buffer may be overwritten next round
+        dma_wait();
+        __syncthreads();
+
+        if (c == p.nchunks - 1) {
+            // ---------------- epilogue of unit (t, yb) ----------------
+            const int grp = p.out_stats ? (int)(((long)t * G_BM) / p.px_per_group) : 0;
+            if (p.out_stats && red_live && (grp != red_grp || yb != red_yb)) stats_flush();
+            float bq[4][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = n0 + nt * 16 + cq + r;
+                    bq[nt][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+                }
+            float ssum[4][4], ssq[4][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
+            char* obase = p.out + (((size_t)t * G_BM + wm * 128 + (lane & 15)) * p.Cout_p + n0 + (lane >> 4) * 8) * 2;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                float v[4][4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[nt][r] = acc[mt][nt][r] + bq[nt][r];
+                        acc[mt][nt][r] = 0.f;
+                        ssum[nt][r] += v[nt][r]; ssq[nt][r] += v[nt][r] * v[nt][r];
+                    }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    // after the transpose lane (row g = lane>>4) owns channels n0 + pr*32 + 8g .. +7 of its pixel
+                    char* oaddr = obase + (size_t)mt * 16 * p.Cout_p * 2 + pr * 64;
+                    const bool vc = n0 + pr * 32 + (lane >> 4) * 8 < p.Cout_p;
+                    if (p.accumulate) {
+                        // data gradient added to an existing one: in fp32 on the transposed layout (raw dwords transposed), rounded once
+                        const uint4 oldq = vc ? *(const uint4*)oaddr : make_uint4(0, 0, 0, 0);
+                        unsigned t0[4], t1[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            auto x32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * pr][r]), __float_as_uint(v[2 * pr + 1][r]), false, false);
+                            auto x16 = __builtin_amdgcn_permlane16_swap(x32[0], x32[1], false, false);
+                            t0[r] = x16[0]; t1[r] = x16[1];
+                        }
+                        float o8[8], w8[8];
+                        Gran<bf16_t>::unpack(oldq, o8);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { w8[r] = __uint_as_float(t0[r]) + o8[r]; w8[4 + r] = __uint_as_float(t1[r]) + o8[4 + r]; }
+                        if (vc) *(uint4*)oaddr = Gran<bf16_t>::pack(w8);
+                    } else {
+                        const unsigned p0 = pack_bf16x2(v[2 * pr][0], v[2 * pr][1]), p1 = pack_bf16x2(v[2 * pr][2], v[2 * pr][3]);
+                        const unsigned q0 = pack_bf16x2(v[2 * pr + 1][0], v[2 * pr + 1][1]), q1 = pack_bf16x2(v[2 * pr + 1][2], v[2 * pr + 1][3]);
+                        auto a32 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                        auto a16 = __builtin_amdgcn_permlane16_swap(a32[0], a32[1], false, false);
+                        auto b32 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                        auto b16 = __builtin_amdgcn_permlane16_swap(b32[0], b32[1], false, false);
+                        if (vc) *(uint4*)oaddr = make_uint4(a16[0], b16[0], a16[1], b16[1]);
+                    }
+                }
+            }
+            if (p.out_stats) {
+                // lanes -> row sums -> this wave's LDS slots (only this wave touches them until the flush)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sa = g_row16_sum(ssum[nt][r]), sb = g_row16_sum(ssq[nt][r]);
+                        if ((lane & 15) == 0) {
+                            red[(wave * 2 + 0) * 64 + nt * 16 + cq + r] += sa;
+                            red[(wave * 2 + 1) * 64 + nt * 16 + cq + r] += sb;
+                        }
+                    }
+                red_live = true; red_grp = grp; red_yb = yb;
+            }
+        }
+        u = u2; c = c2; t = t2; yb = yb2;
+    }
+    if (p.out_stats && red_live) stats_flush();
+}
+
+int g_conv_gemm = 1;                 // big 1x1 convolutions through conv_gemm1x1_kernel; tuning: mfc_set_flag(23, v)
+int g_conv_gemm_minc = 128;          // smallest Cin / Cout (channels) sent there; tuning: mfc_set_flag(24, n)
+
+bool gemm1x1_eligible(const mfc_conv_desc* d) {
+    if (!g_conv_gemm || d->dtype != MFC_BF16) return false;
+    if (d->TA != 1 || d->TB != 1 || d->in_stride != 1 || d->dh0 != 0 || d->dw0 != 0) return false;
+    if (d->out_sh != 1 || d->out_sw != 1 || d->out_oh != 0 || d->out_ow != 0) return false;
+    if (d->Hl != d->Hout || d->Wl != d->Wout || d->Hin != d->Hout || d->Win != d->Wout) return false;
+    if (d->in_coef) return false;
+    if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin < g_conv_gemm_minc || d->Cout < g_conv_gemm_minc) return false;
+    const long M = (long)d->N * d->Hout * d->Wout;
+    if (M % G_BM || M / G_BM > 0x3fffffff) return false;
+    if (d->out_stats) {
+        if (d->images_per_group <= 0 || d->N % d->images_per_group) return false;
+        if (((long)d->images_per_group * d->Hout * d->Wout) % G_BM) return false;      // a pixel tile never straddles a statistics group
+    }
+    return true;
+}
+
+int gemm1x1_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
+    const int Cin_g = d->Cin_p / 8;
+    out->KG = G_KG; out->nchunks = ceil_div(Cin_g, G_KG); out->NT16 = G_BN; out->Yblocks = ceil_div(d->Cout, G_BN);
+    out->nslots = G_KG; out->TA = 1; out->TB = 1; out->TAS = 1; out->lds_bytes = G_LDS;
+    out->bytes = (int64_t)out->nchunks * out->Yblocks * G_BBYTES;
+    const int ntiles = (int)(((long)d->N * d->Hout * d->Wout) / G_BM);
+    out->MT = 8; out->TH = 1; out->TW = G_BM; out->grid = ntiles < 256 ? ntiles : 256; out->per_block = ceil_div(ntiles, out->grid); out->NW = 8; out->pad_ = 0;
+    return MFC_OK;
+}
+
+int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st) {
+    if (!d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
+    GemmK k;
+    k.in = (const char*)d->in; k.wp = (const char*)d->wp; k.out = (char*)d->out; k.bias = d->bias; k.out_stats = d->out_stats;
+    k.M = d->N * d->Hout * d->Wout; k.Cin_p = d->Cin_p; k.Cin_g = d->Cin_p / 8; k.Cout_p = d->Cout_p; k.Cout = d->Cout;
+    k.nchunks = ceil_div(k.Cin_g, G_KG); k.Yblocks = ceil_div(d->Cout, G_BN);
+    k.ntiles = k.M / G_BM;
+    int grid = k.ntiles < 256 ? k.ntiles : 256;
+    k.tiles_per_block = ceil_div(k.ntiles, grid);
+    grid = ceil_div(k.ntiles, k.tiles_per_block);
+    k.G = d->out_stats ? d->N / d->images_per_group : 1;
+    k.accumulate = d->accumulate;
+    k.px_per_group = d->out_stats ? d->images_per_group * d->Hout * d->Wout : k.M;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (g_mfc_prof_on) {
+        const double flops = 2.0 * k.M * (double)d->Cout * (double)d->Cin;
+        const double bytes = (double)k.M * (k.Cin_p + k.Cout_p) * 2.0;
+        mfc_prof_before(st, 0 * 128 + 64 + 40, flops, bytes);       // conv family, bf16, slot 40 (conv_gemm1x1_kernel)
+    }
+    hipLaunchKernelGGL(conv_gemm1x1_kernel, dim3(grid), dim3(512), G_LDS, st, k);
+    if (g_mfc_prof_on) mfc_prof_after(st);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}

@@ -713,7 +713,13 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
     return MFC_OK;
 }
 
+// conv_gemm1x1.hip
+bool gemm1x1_eligible(const mfc_conv_desc* d);
+int gemm1x1_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
+int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st);
+
 extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
+    if (d && out && gemm1x1_eligible(d)) return gemm1x1_layout(d, out);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     mfc_conv_desc t = *d;
     if (!t.in) t.in = (const void*)16;
@@ -729,6 +735,7 @@ extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
 }
 
 extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
+    if (d && gemm1x1_eligible(d)) { mfc_conv_layout l; gemm1x1_layout(d, &l); return l.lds_bytes; }
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
     return rc < 0 ? rc : (int)lds;
@@ -763,6 +770,7 @@ static int conv_dispatch(const ConvK& k, int MT, int PM, int NW, size_t lds, int
 }
 
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
+    if (d && gemm1x1_eligible(d)) return gemm1x1_launch(d, (hipStream_t)stream);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
     if (rc < 0) return rc;

@@ -39,7 +39,7 @@ int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
-extern int g_conv_wres;
+extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc;
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
@@ -62,6 +62,8 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 20) { g_conv_wres = value; return 0; }
     if (id == 21) { g_wgrad_maxpx = value; return 0; }
     if (id == 22) return mfc_set_probe_streams(value);
+    if (id == 23) { g_conv_gemm = value; return 0; }
+    if (id == 24) { g_conv_gemm_minc = value; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }

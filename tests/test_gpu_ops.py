@@ -44,6 +44,7 @@ CONV_CASES = [  # N, Cin, Cout, k, s, H, W
     (2, 15, 15, 11, 1, 32, 48), (1, 22, 15, 11, 1, 24, 40), (2, 15, 5, 1, 1, 16, 16), (1, 48, 96, 3, 2, 23, 30),
     (2, 32, 32, 3, 1, 30, 40), (1, 128, 256, 3, 2, 30, 40), (2, 192, 48, 1, 1, 8, 10),
     (3, 64, 256, 1, 1, 40, 56), (2, 32, 96, 3, 1, 24, 40),      # single-stage launches with several cout blocks (weights of all blocks resident)
+    (2, 480, 480, 1, 1, 16, 24), (2, 256, 200, 1, 1, 16, 16), (1, 136, 520, 1, 1, 16, 32), (3, 720, 720, 1, 1, 16, 32),   # big 1x1: the plain-GEMM kernel (bf16)
 ]
 
 
@@ -90,8 +91,32 @@ def test_conv_fused_bn_relu_input_and_stats(M, dtype, cfg):
         assert relerr(st[g, 1], (r * r).sum((0, 2, 3))) < 5 * TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", [(480, 480, 16, 16), (136, 520, 16, 32), (256, 720, 8, 32)])
+def test_conv1x1_bias_and_stats_without_input_transform(M, dtype, cfg):
+    """last_layer[0] (hrnet.py:334-351): 1x1 conv + bias whose epilogue feeds the following BatchNorm's statistics; in bf16 this
+    shape class runs in the plain-GEMM kernel (conv_gemm1x1.hip), in fp32 in the general one."""
+    _, L, ops = M
+    Cin, Cout, H, W = cfg
+    N, G = 6, 3
+    x = rnd(dtype, N, Cin, H, W, seed=14)
+    w = rnd(dtype, Cout, Cin, 1, 1, seed=15, scale=1.0 / np.sqrt(Cin))
+    b = rnd(torch.float32, Cout, seed=16)
+    ref = F.conv2d(x, w, b)
+    stats = torch.zeros(L.STAT_REPLICAS, G, 2, ops.rup(Cout, 8), device="cuda")
+    y = ops.conv2d(ops.to_nhwc(x, dtype), w.cuda(), 1, 1, bias=b.cuda(), ipg=2, stats=stats)
+    assert relerr(ops.to_nchw(y, Cout).cpu(), ref) < TOL[dtype]
+    st = stats.sum(0).cpu()
+    for g in range(G):
+        r = ref[g * 2:(g + 1) * 2]
+        assert relerr(st[g, 0, :Cout], r.sum((0, 2, 3))) < 5 * TOL[dtype]
+        assert relerr(st[g, 1, :Cout], (r * r).sum((0, 2, 3))) < 5 * TOL[dtype]
+    assert float(st[:, :, Cout:].abs().max() if st.shape[2] > Cout else 0.0) == 0.0
+
+
 DG_CASES = [(2, 48, 48, 3, 1, 24, 40), (2, 64, 64, 3, 2, 32, 48), (1, 48, 96, 3, 2, 23, 30), (2, 96, 48, 1, 1, 15, 20),
-            (1, 22, 15, 11, 1, 24, 40), (2, 192, 384, 3, 2, 30, 40), (2, 256, 96, 3, 2, 16, 24)]
+            (1, 22, 15, 11, 1, 24, 40), (2, 192, 384, 3, 2, 30, 40), (2, 256, 96, 3, 2, 16, 24),
+            (2, 256, 192, 1, 1, 16, 16), (1, 480, 480, 1, 1, 16, 32)]      # (1x1 with >= 128 channels: plain-GEMM kernel, incl. accumulate)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -12,9 +12,9 @@ def time_op(op, reps=10):
         rc = L.lib.mfc_program_profile(prog, 1, reps, ms, L.stream_ptr()); assert rc == 0, rc
     return ms[0] * 1e3
 
-SHAPES = [(24, 32, 32, 3, 120, 160), (24, 18, 18, 3, 120, 160), (24, 48, 48, 3, 120, 160), (24, 32, 64, 3, 60, 80), (24, 64, 32, 1, 120, 160), (24, 32, 96, 1, 60, 80), (8, 15, 15, 3, 480, 640), (8, 15, 15, 11, 480, 640), (24, 64, 256, 1, 120, 160)]
+SHAPES = [(24, 480, 480, 1, 120, 160), (24, 720, 720, 1, 120, 160), (24, 256, 64, 1, 120, 160), (24, 256, 256, 1, 120, 160), (24, 128, 128, 1, 60, 80), (24, 192, 384, 1, 30, 40)]
 SHAPES_OLD = [(24, 32, 32, 3, 120, 160), (24, 64, 64, 3, 60, 80), (24, 128, 128, 3, 30, 40), (24, 256, 256, 3, 15, 20), (24, 480, 480, 1, 120, 160), (24, 64, 256, 1, 120, 160), (24, 96, 96, 3, 60, 80), (24, 192, 192, 3, 30, 40), (24, 384, 384, 3, 15, 20), (8, 15, 15, 11, 480, 640), (8, 15, 15, 3, 480, 640)]
-COMBOS = [0, 1]           # flag 20: all cout blocks' weights resident for single-stage launches
+COMBOS = [0, 1]           # flag 23: big 1x1 convolutions through the plain-GEMM kernel
 def main():
   for (N, Cin, Cout, k, H, W) in SHAPES:
       pad = k // 2
@@ -24,16 +24,16 @@ def main():
       flops = 2.0 * N * H * W * Cout * Cin * k * k
       line = f"{(N,Cin,Cout,k,H,W)}"
       for nw8 in COMBOS:
-          L.lib.mfc_set_flag(20, nw8)
+          L.lib.mfc_set_flag(23, nw8); L.lib.mfc_set_flag(24, 64)
           d = L.ConvDesc(x.data_ptr(), 0, out.data_ptr(), 0, 0, 0, L.BF16, N, H, W, x.shape[3], Cin, H, W, out.shape[3], Cout, H, W, k, k, -pad, -pad, 1, 1, 1, 0, 0, 0, N, 0, 0, 0)
           try:
               wp = ops.pack_weight(w, d, "fwd"); d.wp = wp.data_ptr()
               lay = L.conv_layout(d)
               op = L.Op(); op.kind = L.OP_CONV; op.u.conv = d
               t = time_op(op)
-              line += f" | wres={nw8}: NW{lay.NW} MT{lay.MT} KG{lay.KG} chunks{lay.nchunks} TAS{lay.TAS} {lay.lds_bytes//1024}K g{lay.grid} {t:6.1f}us {flops/t/1e6:4.0f}TF"
+              line += f" | gemm={nw8}: NW{lay.NW} MT{lay.MT} KG{lay.KG} chunks{lay.nchunks} TAS{lay.TAS} {lay.lds_bytes//1024}K g{lay.grid} {t:6.1f}us {flops/t/1e6:4.0f}TF"
           except Exception as e:
-              line += f" | wres={nw8}: n/a {e}"
+              line += f" | gemm={nw8}: n/a {e}"
       print(line, flush=True)
 
 if __name__ == "__main__":
