@@ -12,7 +12,7 @@ def time_op(op, reps=10):
         rc = L.lib.mfc_program_profile(prog, 1, reps, ms, L.stream_ptr()); assert rc == 0, rc
     return ms[0] * 1e3
 
-SHAPES = [(24, 480, 480, 1, 120, 160), (24, 720, 720, 1, 120, 160), (24, 256, 64, 1, 120, 160), (24, 256, 256, 1, 120, 160), (24, 128, 128, 1, 60, 80), (24, 192, 384, 1, 30, 40)]
+SHAPES = [(24, 64, 256, 1, 120, 160), (24, 64, 128, 1, 120, 160), (24, 480, 480, 1, 120, 160), (24, 720, 720, 1, 120, 160), (24, 256, 64, 1, 120, 160), (24, 256, 256, 1, 120, 160), (24, 128, 128, 1, 60, 80), (24, 192, 384, 1, 30, 40)]
 SHAPES_OLD = [(24, 32, 32, 3, 120, 160), (24, 64, 64, 3, 60, 80), (24, 128, 128, 3, 30, 40), (24, 256, 256, 3, 15, 20), (24, 480, 480, 1, 120, 160), (24, 64, 256, 1, 120, 160), (24, 96, 96, 3, 60, 80), (24, 192, 192, 3, 30, 40), (24, 384, 384, 3, 15, 20), (8, 15, 15, 11, 480, 640), (8, 15, 15, 3, 480, 640)]
 COMBOS = [0, 1]           # flag 23: big 1x1 convolutions through the plain-GEMM kernel
 def main():
