@@ -44,7 +44,7 @@ CONV_CASES = [  # N, Cin, Cout, k, s, H, W
     (2, 15, 15, 11, 1, 32, 48), (1, 22, 15, 11, 1, 24, 40), (2, 15, 5, 1, 1, 16, 16), (1, 48, 96, 3, 2, 23, 30),
     (2, 32, 32, 3, 1, 30, 40), (1, 128, 256, 3, 2, 30, 40), (2, 192, 48, 1, 1, 8, 10),
     (3, 64, 256, 1, 1, 40, 56), (2, 32, 96, 3, 1, 24, 40),      # single-stage launches with several cout blocks (weights of all blocks resident)
-    (2, 480, 480, 1, 1, 16, 24), (2, 256, 200, 1, 1, 16, 16), (1, 136, 520, 1, 1, 16, 32), (3, 720, 720, 1, 1, 16, 32),   # big 1x1: the plain-GEMM kernel (bf16)
+    (2, 480, 480, 1, 1, 16, 24), (2, 256, 200, 1, 1, 16, 16), (1, 136, 520, 1, 1, 16, 32), (3, 720, 720, 1, 1, 16, 32), (2, 64, 256, 1, 1, 16, 16),   # big 1x1: the plain-GEMM kernel (bf16)
 ]
 
 
@@ -116,7 +116,7 @@ def test_conv1x1_bias_and_stats_without_input_transform(M, dtype, cfg):
 
 DG_CASES = [(2, 48, 48, 3, 1, 24, 40), (2, 64, 64, 3, 2, 32, 48), (1, 48, 96, 3, 2, 23, 30), (2, 96, 48, 1, 1, 15, 20),
             (1, 22, 15, 11, 1, 24, 40), (2, 192, 384, 3, 2, 30, 40), (2, 256, 96, 3, 2, 16, 24),
-            (2, 256, 192, 1, 1, 16, 16), (1, 480, 480, 1, 1, 16, 32)]      # (1x1 with >= 128 channels: plain-GEMM kernel, incl. accumulate)
+            (2, 256, 192, 1, 1, 16, 16), (1, 480, 480, 1, 1, 16, 32), (2, 256, 64, 1, 1, 16, 16)]      # (1x1 with >= 128 channels: plain-GEMM kernel, incl. accumulate)
 
 
 @pytest.mark.parametrize("dtype", DT)
