@@ -1,0 +1,55 @@
+"""bench.py end to end on the GPU box: the JSON contract of the single-GPU line, and the N > 1 code path (global-batch loss,
+bucketed gradient all-reduce started from inside the backward) rehearsed with two gloo ranks sharing the one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+SMALL = ["--steps", "3", "--warmup", "1", "--batch", "2", "--height", "96", "--width-px", "128", "--no-cpu-baseline"]
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    _need_gpu()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "frames/s" and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 0.0 < d["config"]["final_loss"] < 20.0
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    _need_gpu()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 4 * 3 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]
+    assert 0.0 < d["config"]["final_loss"] < 20.0
