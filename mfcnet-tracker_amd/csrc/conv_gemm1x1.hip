@@ -36,8 +36,10 @@ __device__ inline float g_row16_sum(float v) {      // sum over the 16 lanes of 
 constexpr int G_BM = 256, G_BN = 256, G_KG = 8;                 // pixels, couts, granules (of 8 channels) per stage
 constexpr int G_ABYTES = G_BM * G_KG * 16, G_BBYTES = G_KG * G_BN * 16;      // 32 KiB each
 constexpr int G_OFF_A0 = 0, G_OFF_A1 = G_ABYTES, G_OFF_B0 = 2 * G_ABYTES, G_OFF_B1 = 2 * G_ABYTES + G_BBYTES;
-constexpr int G_OFF_RED = 2 * G_ABYTES + 2 * G_BBYTES;        // float [8 waves][2][64]
-constexpr int G_LDS = G_OFF_RED + 8 * 2 * 64 * 4;
+constexpr int G_MAXYB = 4;                                       // cout blocks whose statistics are kept in LDS side by side
+constexpr int G_RED1 = 8 * 2 * 64;                               // floats of one block's sums: [8 waves][2][64]
+constexpr int G_OFF_RED = 2 * G_ABYTES + 2 * G_BBYTES;        // float [G_MAXYB][8 waves][2][64]
+constexpr int G_LDS = G_OFF_RED + G_MAXYB * G_RED1 * 4;
 
 __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,7 +51,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
     const int t0 = Lb * p.tiles_per_block;
     const int ntl = min(p.tiles_per_block, p.ntiles - t0);
     if (ntl <= 0) return;
-    const bool ybfast = (p.out_stats == nullptr);           // with statistics: cout block slowest, so that the sums stay in LDS over many tiles
+    // cout block fastest: the Yblocks units of a pixel tile run back to back and the re-reads of the tile hit L2.  The statistics of
+    // up to G_MAXYB blocks are kept side by side in LDS across tiles; with more blocks the order flips (block slowest)
+    const bool ybfast = (p.out_stats == nullptr) || p.Yblocks <= G_MAXYB;
     const int nunits = ntl * p.Yblocks;
     const int S = nunits * p.nchunks;
     const int cq = (lane >> 4) * 4;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
     const int a_k0 = (((lane >> 4)) ^ (lane & 7)) * 16, a_k1 = ((4 + (lane >> 4)) ^ (lane & 7)) * 16;
     const int b_off = ((lane >> 4) * G_BN + wn * 64 + (lane & 15)) * 16;
 
-    for (int i = tid; i < 8 * 2 * 64; i += 512) red[i] = 0.f;
+    for (int i = tid; i < G_MAXYB * G_RED1; i += 512) red[i] = 0.f;
     int t, yb;
     unit_of(0, t, yb);
     dma_stage(t, 0, yb, 0);
@@ -99,17 +103,19 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
 
     int u = 0, c = 0;
     int red_grp = -1, red_yb = -1; bool red_live = false;
-    auto stats_flush = [&]() {          // every wave has added its row sums to red[wave]; sum the two pixel halves, publish, clear
+    auto stats_flush = [&]() {          // every wave has added its row sums to red[yb][wave]; sum the two pixel halves, publish, clear
         __syncthreads();
-        if (tid < 512) {
+        const int y0 = ybfast ? 0 : red_yb, y1 = ybfast ? p.Yblocks : red_yb + 1;
+        for (int y = y0; y < y1; ++y) {
+            const float* rd = red + (ybfast ? y : 0) * G_RED1;
             const int which = tid >> 8, cl = tid & 255;
             const int w0 = (cl >> 6) * 2, ch = cl & 63;
-            const float s = red[(w0 * 2 + which) * 64 + ch] + red[((w0 + 1) * 2 + which) * 64 + ch];
-            const int co = red_yb * G_BN + cl;
+            const float s = rd[(w0 * 2 + which) * 64 + ch] + rd[((w0 + 1) * 2 + which) * 64 + ch];
+            const int co = y * G_BN + cl;
             if (co < p.Cout_p) atomicAdd(p.out_stats + (((size_t)(Lb % MFC_R) * p.G + red_grp) * 2 + which) * p.Cout_p + co, s);
         }
         __syncthreads();
-        for (int i = tid; i < 8 * 2 * 64; i += 512) red[i] = 0.f;
+        for (int i = tid; i < G_MAXYB * G_RED1; i += 512) red[i] = 0.f;
         __syncthreads();
         red_live = false;
     };
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
         if (c == p.nchunks - 1) {
             // ---------------- epilogue of unit (t, yb) ----------------
             const int grp = p.out_stats ? (int)(((long)t * G_BM) / p.px_per_group) : 0;
-            if (p.out_stats && red_live && (grp != red_grp || yb != red_yb)) stats_flush();
+            if (p.out_stats && red_live && (grp != red_grp || (!ybfast && yb != red_yb))) stats_flush();
             float bq[4][4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -213,8 +219,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
                     for (int r = 0; r < 4; ++r) {
                         const float sa = g_row16_sum(ssum[nt][r]), sb = g_row16_sum(ssq[nt][r]);
                         if ((lane & 15) == 0) {
-                            red[(wave * 2 + 0) * 64 + nt * 16 + cq + r] += sa;
-                            red[(wave * 2 + 1) * 64 + nt * 16 + cq + r] += sb;
+                            float* rw = red + (ybfast ? yb : 0) * G_RED1;
+                            rw[(wave * 2 + 0) * 64 + nt * 16 + cq + r] += sa;
+                            rw[(wave * 2 + 1) * 64 + nt * 16 + cq + r] += sb;
                         }
                     }
                 red_live = true; red_grp = grp; red_yb = yb;
