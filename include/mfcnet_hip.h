@@ -396,7 +396,8 @@ int mfc_program_profile(const mfc_op* ops, int32_t n, int32_t reps, float* ms_ou
  *   family 0 = conv_igemm_kernel<T, NT, MT, PMAX>: slot = ntIndex*4 + variant, NT in {1,2,3,4,6} -> ntIndex 0..4,
  *              variant 0..3 = <MT,PMAX> in {<4,3>, <4,6>, <2,4>, <2,10>}, +20 for the 8-wave instantiations (NW = 8)
  *              (one bucket per kernel instantiation, as rocprof sees it); slot 40 = conv_gemm1x1_kernel (big 1x1 convolutions, bf16)
- *   family 1 = weight gradient: slot 0..2 generic kernel (TPW 8/16/28), 8..10 fast kernel (TB 1/3/11), 16..17 wave kernel (TB 3/11) */
+ *   family 1 = weight gradient: slot 0..2 generic kernel (TPW 8/16/28), 8..10 fast kernel (TB 1/3/11), 16..17 wave kernel (TB 3/11),
+ *              24 = wgrad_gemm1x1_kernel */
 #define MFC_PROF_BUCKETS 256
 typedef struct { double ms[MFC_PROF_BUCKETS]; double flops[MFC_PROF_BUCKETS]; double bytes[MFC_PROF_BUCKETS]; int64_t launches[MFC_PROF_BUCKETS]; } mfc_prof_result;
 int mfc_prof_enable(int on);
@@ -416,7 +417,9 @@ int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded eve
  *  21  wgrad: output pixels per workgroup above which the pixel axis is split further than switch 11 asks (6000; 0 = never)
  *  22  lanes: measure which side streams really overlap with the caller's stream before choosing them (1; see runtime.hip)
  *  23  conv: big 1x1 / stride-1 convolutions without input transform run as a plain GEMM (conv_gemm1x1.hip) (1)
- *  24  conv: smallest Cin and Cout sent to that GEMM (128) */
+ *  24  conv: smallest Cin and Cout sent to that GEMM (128)
+ *  25  wgrad: 1x1 weight gradients without input transform as a split-K GEMM (wgrad_gemm1x1.hip) (1)
+ *  26  wgrad: smallest Cin and Cout sent to that GEMM (64) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

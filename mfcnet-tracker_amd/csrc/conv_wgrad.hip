@@ -39,7 +39,7 @@ int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
-extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc;
+extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc;
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
@@ -64,6 +64,8 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 22) return mfc_set_probe_streams(value);
     if (id == 23) { g_conv_gemm = value; return 0; }
     if (id == 24) { g_conv_gemm_minc = value; return 0; }
+    if (id == 25) { g_wgrad_gemm = value; return 0; }
+    if (id == 26) { g_wgrad_gemm_minc = value; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
@@ -1054,11 +1056,20 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only, 
     return MFC_ERR_UNSUPPORTED;
 }
 
+// wgrad_gemm1x1.hip
+bool wgrad_gemm1x1_eligible(const mfc_wgrad_desc* d);
+int wgrad_gemm1x1_parts(const mfc_wgrad_desc* d);
+int wgrad_gemm1x1_launch(const mfc_wgrad_desc* d, hipStream_t st);
+
 static int wgrad_any(const mfc_wgrad_desc* d, void* stream, int* parts_only) {
     if (!d || !d->x || !d->dy || !d->dwp) return MFC_ERR_INVALID_ARG;
     if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
     if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin > d->Cin_p || d->Cout > d->Cout_p) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->TA <= 0 || d->TB <= 0 || d->in_stride < 1 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
+    if (wgrad_gemm1x1_eligible(d)) {
+        if (parts_only) { *parts_only = wgrad_gemm1x1_parts(d); return MFC_OK; }
+        return wgrad_gemm1x1_launch(d, (hipStream_t)stream);
+    }
     {
         int rcf = wgrad_wave(d, (hipStream_t)stream, parts_only);
         if (rcf != MFC_ERR_UNSUPPORTED) return rcf;

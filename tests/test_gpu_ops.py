@@ -138,7 +138,8 @@ def test_conv_dgrad(M, case, dtype):
 
 WG_CASES = [(2, 48, 48, 3, 1, 24, 40), (2, 3, 64, 3, 2, 64, 96), (2, 96, 96, 3, 1, 30, 40), (3, 96, 192, 3, 2, 15, 20),
             (2, 384, 384, 3, 1, 15, 20), (2, 256, 64, 1, 1, 16, 24), (1, 720, 720, 1, 1, 12, 20), (2, 720, 5, 1, 1, 16, 24),
-            (2, 15, 15, 11, 1, 32, 48), (1, 22, 15, 11, 1, 24, 40), (1, 48, 96, 3, 2, 23, 30), (2, 32, 64, 3, 1, 17, 21)]
+            (2, 15, 15, 11, 1, 32, 48), (1, 22, 15, 11, 1, 24, 40), (1, 48, 96, 3, 2, 23, 30), (2, 32, 64, 3, 1, 17, 21),
+            (4, 480, 480, 1, 1, 16, 16), (3, 136, 520, 1, 1, 16, 32), (2, 720, 720, 1, 1, 24, 32), (4, 256, 128, 1, 1, 16, 32)]      # (1x1, >= 128 channels: split-K GEMM kernel in bf16)
 
 
 @pytest.mark.parametrize("tr", [1, 0])
@@ -176,6 +177,29 @@ def test_wgrad_fused_input_transform(M):
     y.backward(dy)
     dw = ops.conv2d_wgrad(ops.to_nhwc(x), ops.to_nhwc(dy), Cout, Cin, 3, 1, in_coef=coef.cuda(), in_relu=True)
     assert relerr(dw.cpu(), w.grad) < 2e-4
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", [(64, 256, 16, 32), (136, 520, 16, 16), (256, 64, 8, 32)])
+def test_wgrad_1x1_fused_input_transform_groups(M, dtype, cfg):
+    """1x1 weight gradient with the producer's BatchNorm + ReLU applied to x on the fly, one coefficient set per statistics group
+    (layer1's 64 -> 256 convolutions, hrnet.py:95-115); in bf16 this is the split-K GEMM kernel (wgrad_gemm1x1.hip)."""
+    _, L, ops = M
+    Cin, Cout, H, W = cfg
+    N, G = 6, 3
+    x = rnd(dtype, N, Cin, H, W, seed=21)
+    scale, shift = torch.rand(G, Cin) + 0.5, torch.randn(G, Cin) * 0.3
+    coef = torch.zeros(G, 4, ops.rup(Cin, 8))
+    coef[:, 0, :Cin], coef[:, 1, :Cin] = scale, shift
+    xa = torch.cat([F.relu(x[g * 2:(g + 1) * 2] * scale[g].view(1, -1, 1, 1) + shift[g].view(1, -1, 1, 1)) for g in range(G)])
+    if dtype == torch.bfloat16:
+        xa = xa.bfloat16().float()
+    w = rnd(dtype, Cout, Cin, 1, 1, seed=22, scale=0.05).requires_grad_(True)
+    y = F.conv2d(xa, w, None)
+    dy = rnd(dtype, *y.shape, seed=23)
+    y.backward(dy)
+    dw = ops.conv2d_wgrad(ops.to_nhwc(x, dtype), ops.to_nhwc(dy, dtype), Cout, Cin, 1, 1, in_coef=coef.cuda(), in_relu=True, ipg=2)
+    assert relerr(dw.cpu(), w.grad) < TOL[dtype]
 
 
 def test_bn_finalize_matches_batch_norm(M):
