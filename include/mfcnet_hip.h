@@ -69,7 +69,7 @@ typedef enum {
  *   dgrad of stride 1   :  flipped taps (done by the weight packer), dh0=-(k-1-p)
  *   dgrad of stride 2   :  four launches, one per output parity class
  * Wp is the packed weight image produced by mfc_pack_weights.
- * bf16 1x1 / stride-1 launches without input transform, with >= 128 input and output channels and a pixel count that is a
+ * bf16 1x1 / stride-1 launches with >= 128 input and output channels (or 64 -> >= 256) and a pixel count that is a
  * multiple of 256 (last_layer[0], hrnet.py:334-351, and its data gradient) run as a plain GEMM with 256x256 tiles
  * (conv_gemm1x1.hip); mfc_conv2d_layout reports the weight blocking of whichever kernel will run.
  * Optional epilogue: + bias[co]; out = acc + out (accumulate); per-(group,channel)

@@ -12,6 +12,7 @@
 //     image), the activations land as [pixel][granule ^ (pixel & 7)] (XOR swizzle: the DMA writes lane-contiguous LDS, so the
 //     swizzle is applied to the SOURCE granule each lane fetches -- free), which makes the fragment reads conflict free;
 //   * persistent workgroups over contiguous pixel-tile ranges; the input is read once per 256-channel block;
+//   * the fused input transform (BatchNorm + ReLU of the producer) is applied to the activation tile in place in LDS after it landed;
 //   * epilogue as in conv_igemm: + bias, per-(group, channel) sum / sum of squares, bf16 rows transposed across the four 16-lane
 //     groups (v_permlane32_swap / v_permlane16_swap) so that every lane stores 16 contiguous bytes.
 // Dispatched from mfc_conv2d_fwd / mfc_conv2d_layout (conv_igemm.hip) when gemm1x1_eligible(); everything else, and the
@@ -19,7 +20,8 @@
 #include "common.h"
 
 struct GemmK {
-    const char* in; const char* wp; char* out; const float* bias; float* out_stats;
+    const char* in; const char* wp; char* out; const float* bias; float* out_stats; const float* in_coef;
+    int in_relu;
     int M, Cin_p, Cin_g, Cout_p, Cout;
     int nchunks, Yblocks, ntiles, tiles_per_block;
     int px_per_group, G, accumulate;
@@ -39,7 +41,9 @@ constexpr int G_OFF_A0 = 0, G_OFF_A1 = G_ABYTES, G_OFF_B0 = 2 * G_ABYTES, G_OFF_
 constexpr int G_MAXYB = 4;                                       // cout blocks whose statistics are kept in LDS side by side
 constexpr int G_RED1 = 8 * 2 * 64;                               // floats of one block's sums: [8 waves][2][64]
 constexpr int G_OFF_RED = 2 * G_ABYTES + 2 * G_BBYTES;        // float [G_MAXYB][8 waves][2][64]
-constexpr int G_LDS = G_OFF_RED + G_MAXYB * G_RED1 * 4;
+constexpr int G_OFF_COEF = G_OFF_RED + G_MAXYB * G_RED1 * 4;     // float [G][2][Cin_p]: scale / shift of the fused input transform
+constexpr int G_COEF_FLOATS = 3072;
+constexpr int G_LDS = G_OFF_COEF + G_COEF_FLOATS * 4;
 
 __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,11 +124,45 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
         red_live = false;
     };
 
+    // fused input transform x' = relu?(x * scale[g, ci] + shift[g, ci]) (the producer's BatchNorm + ReLU): the tile arrives raw by DMA
+    // and is transformed in place in LDS, 4 granules per thread and stage
+    float* cfl = (float*)(smem + G_OFF_COEF);
+    if (p.in_coef) {
+        for (int i = tid; i < p.G * 2 * p.Cin_p; i += 512) {
+            const int g = i / (2 * p.Cin_p), r = i - g * 2 * p.Cin_p;
+            cfl[i] = p.in_coef[(size_t)g * 4 * p.Cin_p + r];          // rows 0 (scale) and 1 (shift) of [G][4][Cin_p]
+        }
+        __syncthreads();
+    }
+    auto transform = [&](int par, int tt, int cc) {
+        char* At = smem + (par ? G_OFF_A1 : G_OFF_A0);
+        const float* sc = cfl + (size_t)(((long)tt * G_BM) / p.px_per_group) * 2 * p.Cin_p;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + k * 512;                      // granule slot: pixel idx >> 3, position idx & 7
+            const int pl = idx >> 3, cg = cc * G_KG + ((idx & 7) ^ (pl & 7));
+            if (cg < p.Cin_g) {
+                float f[8];
+                Gran<bf16_t>::unpack(*(const uint4*)(At + idx * 16), f);
+                const float4 s0 = *(const float4*)(sc + cg * 8), s1 = *(const float4*)(sc + cg * 8 + 4);
+                const float4 h0 = *(const float4*)(sc + p.Cin_p + cg * 8), h1 = *(const float4*)(sc + p.Cin_p + cg * 8 + 4);
+                const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float tv = f[e] * scv[e] + shv[e];
+                    f[e] = p.in_relu ? relu_nan(tv) : tv;
+                }
+                *(uint4*)(At + idx * 16) = Gran<bf16_t>::pack(f);
+            }
+        }
+    };
+
     for (int s = 0; s < S; ++s) {
         // next stage coordinates
         int u2 = u, c2 = c + 1, t2 = t, yb2 = yb;
         if (c2 == p.nchunks) { c2 = 0; ++u2; if (u2 < nunits) unit_of(u2, t2, yb2); }
         if (s + 1 < S) dma_stage(t2, c2, yb2, (s + 1) & 1);
+        if (p.in_coef) { transform(s & 1, t, c); __syncthreads(); }
 
         // ---------------- compute: 2 k-steps of 32 channels ----------------
         const char* A = smem + ((s & 1) ? G_OFF_A1 : G_OFF_A0) + a_row;
@@ -240,15 +278,15 @@ bool gemm1x1_eligible(const mfc_conv_desc* d) {
     if (d->TA != 1 || d->TB != 1 || d->in_stride != 1 || d->dh0 != 0 || d->dw0 != 0) return false;
     if (d->out_sh != 1 || d->out_sw != 1 || d->out_oh != 0 || d->out_ow != 0) return false;
     if (d->Hl != d->Hout || d->Wl != d->Wout || d->Hin != d->Hout || d->Win != d->Wout) return false;
-    if (d->in_coef) return false;
     if (d->Cin_p % 8 || d->Cout_p % 8) return false;
     // wide enough for the 256-channel tile: >= 128 channels on both sides, or a full 256-channel block from >= 64 (measured:
     // 64 -> 256 at 120x160: 93 -> 74 us; 64 -> 128: 45 -> 49 us; 256 -> 64: 66 -> 94 us)
     if (!((d->Cin >= g_conv_gemm_minc && d->Cout >= g_conv_gemm_minc) || (d->Cin >= 64 && d->Cout >= 256))) return false;
     const long M = (long)d->N * d->Hout * d->Wout;
     if (M % G_BM || M / G_BM > 0x3fffffff) return false;
-    if (d->out_stats) {
+    if (d->out_stats || d->in_coef) {
         if (d->images_per_group <= 0 || d->N % d->images_per_group) return false;
+        if (d->in_coef && (long)(d->N / d->images_per_group) * 2 * d->Cin_p > G_COEF_FLOATS) return false;      // coefficients staged in LDS
         if (((long)d->images_per_group * d->Hout * d->Wout) % G_BM) return false;      // a pixel tile never straddles a statistics group
     }
     return true;
@@ -274,9 +312,11 @@ int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st) {
     int grid = k.ntiles < 256 ? k.ntiles : 256;
     k.tiles_per_block = ceil_div(k.ntiles, grid);
     grid = ceil_div(k.ntiles, k.tiles_per_block);
-    k.G = d->out_stats ? d->N / d->images_per_group : 1;
+    k.in_coef = d->in_coef; k.in_relu = d->in_relu;
+    const bool grouped = d->out_stats || d->in_coef;
+    k.G = grouped ? d->N / d->images_per_group : 1;
     k.accumulate = d->accumulate;
-    k.px_per_group = d->out_stats ? d->images_per_group * d->Hout * d->Wout : k.M;
+    k.px_per_group = grouped ? d->images_per_group * d->Hout * d->Wout : k.M;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

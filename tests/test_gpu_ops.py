@@ -64,7 +64,7 @@ def test_conv_fwd(M, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("cfg", [(48, 96, 3, 20, 28), (64, 256, 1, 40, 56)])
+@pytest.mark.parametrize("cfg", [(48, 96, 3, 20, 28), (64, 256, 1, 40, 56), (64, 256, 1, 16, 32), (136, 520, 1, 16, 16)])   # (last two: plain-GEMM kernel in bf16)
 def test_conv_fused_bn_relu_input_and_stats(M, dtype, cfg):
     """consumer-side BN-apply+ReLU (zero padding AFTER the transform) and the epilogue statistics."""
     _, L, ops = M
