@@ -207,8 +207,20 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
             char* obase = p.out + (((size_t)t * G_BM + wm * 128 + (lane & 15)) * p.Cout_p + n0 + (lane >> 4) * 8) * 2;
+            // accumulate: the old values are requested four pixel tiles (8 stores) ahead, branch-free with a clamped address, so their
+            // latency is paid twice per unit and not once per store
+            uint4 oldv[4][2];
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
+                if (p.accumulate && (mt & 3) == 0) {
+#pragma unroll
+                    for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const bool vc0 = n0 + pr * 32 + (lane >> 4) * 8 < p.Cout_p;
+                            oldv[m2][pr] = *(const uint4*)(obase + (size_t)(mt + m2) * 16 * p.Cout_p * 2 + (vc0 ? pr * 64 : 0));
+                        }
+                }
                 float v[4][4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
                     const bool vc = n0 + pr * 32 + (lane >> 4) * 8 < p.Cout_p;
                     if (p.accumulate) {
                         // data gradient added to an existing one: in fp32 on the transposed layout (raw dwords transposed), rounded once
-                        const uint4 oldq = vc ? *(const uint4*)oaddr : make_uint4(0, 0, 0, 0);
+                        const uint4 oldq = oldv[mt & 3][pr];
                         unsigned t0[4], t1[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
