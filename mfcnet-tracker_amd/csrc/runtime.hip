@@ -434,7 +434,10 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
         int lane = (multi && (g_lanes_on & 1)) ? (ops[i].lane & 0xff) : 0;
         if (lane >= 1 && lane <= MFC_MAX_LANES && g_lane_map[lane]) lane = g_lane_map[lane];
         else if (lane > g_lane_streams) lane = (lane - 1) % g_lane_streams + 1;      // fold the lanes onto the streams in use
-        const bool detached = multi && (g_lanes_on & 2) && (ops[i].lane & MFC_LANE_ASYNC);
+        bool detached = multi && (g_lanes_on & 2) && (ops[i].lane & MFC_LANE_ASYNC);
+        // a detached UNPACK sums the slices of weight gradients launched before it on the detached stream: in order only if that is ONE stream
+        if (detached && ops[i].kind == MFC_OP_UNPACK && g_async_n > 1 && !(g_async_on_lane >= 2 && g_async_on_lane <= MFC_MAX_LANES)) detached = false;
+        if (ops[i].kind == MFC_OP_UNPACK && !detached) lane = 0;      // (then it is ordinary serial work: joins the side lanes and the detached stream)
         hipStream_t st = mainst;
         if (lane >= 2 && lane <= MFC_MAX_LANES) {
             if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; }
@@ -445,7 +448,7 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
         } else if (in_par) {
             join();
         }
-        if (ops[i].kind == MFC_OP_UNPACK && aused) join_async();       // (lane 0: the side lanes were joined just above)
+        if (ops[i].kind == MFC_OP_UNPACK && aused && !detached) join_async();       // (lane 0: the side lanes were joined just above)
         if (detached) {
             hipEvent_t ev = L->aev[aevn]; aevn = (aevn + 1) % MFC_ASYNC_EVENTS;
             (void)hipEventRecord(ev, st);
