@@ -678,7 +678,9 @@ __global__ __launch_bounds__(256, PF == 2 ? 1 : 2) void conv_wgrad_wave_kernel(W
                 float f[E];
                 Gran<T>::unpack(v, f);
 #pragma unroll
-                for (int e = 0; e < E; ++e) f[e] = relu_nan(f[e] * cf[e] + cf[p.gx * 8 + e], relu_floor);
+                // (v_max swallows a NaN of x here, unlike relu_nan: harmless in a weight gradient -- a non-finite activation has already made
+                //  the loss, hence dy and every product below, non-finite; one VALU op per element instead of compare + select)
+                for (int e = 0; e < E; ++e) f[e] = fmaxf(f[e] * cf[e] + cf[p.gx * 8 + e], relu_floor);
                 v = Gran<T>::pack(f);
             }
             if (!S.interior && !(S.xmask & (1u << i))) v = make_uint4(0, 0, 0, 0);

@@ -130,7 +130,12 @@ def test_gradient_buckets_partition_the_backward_program():
     assert ranges[0][0] == 0 and ranges[-1][1] == m._np
     assert all(ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1))
     nseg_unpack = sum(1 for prog, _, _ in pl.bwd_segments for i in range(len(prog)) if prog[i].kind == L.OP_UNPACK)
-    assert sum(len(prog) for prog, _, _ in pl.bwd_segments) - nseg_unpack == len(pl.bwd_prog) - 1      # same records, one unpack per segment vs one in all
+    # same records; one unpack per segment there, chunked detached unpacks (every 48 weight gradients, the rest at the end) in the one program
+    one = [pl.bwd_prog[i] for i in range(len(pl.bwd_prog))]
+    n_one_unpack = sum(1 for o in one if o.kind == L.OP_UNPACK)
+    assert sum(len(prog) for prog, _, _ in pl.bwd_segments) - nseg_unpack == len(one) - n_one_unpack
+    assert n_one_unpack == -(-sum(1 for o in one if o.kind == L.OP_WGRAD) // 48) and one[-1].kind == L.OP_UNPACK
+    assert all((o.lane & L.LANE_ASYNC) for o in one if o.kind == L.OP_UNPACK)       # ... all on the detached stream, behind their launches
     # every parameter's last writer precedes (or is) the end of the segment that owns its bucket
     seg_end, k = [], 0
     for prog, lo, hi in pl.bwd_segments:
