@@ -180,6 +180,8 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
         L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
+    if os.environ.get("MFC_BNRED_BLOCKS"):
+        L.lib.mfc_set_flag(27, int(os.environ["MFC_BNRED_BLOCKS"]))
     if os.environ.get("MFC_CONV_GEMM"):
         L.lib.mfc_set_flag(23, int(os.environ["MFC_CONV_GEMM"]))
     if os.environ.get("MFC_PROBE_STREAMS"):

@@ -419,7 +419,7 @@ int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded eve
  *  23  conv: big 1x1 / stride-1 convolutions without input transform run as a plain GEMM (conv_gemm1x1.hip) (1)
  *  24  conv: smallest Cin and Cout sent to that GEMM (128)
  *  25  wgrad: 1x1 weight gradients without input transform as a split-K GEMM (wgrad_gemm1x1.hip) (1)
- *  26  wgrad: smallest Cin and Cout sent to that GEMM (64) */
+ *  26  wgrad: smallest Cin and Cout sent to that GEMM (64)           27  BN-backward reduce: workgroups per launch (1024; 512-2048 measured equal) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

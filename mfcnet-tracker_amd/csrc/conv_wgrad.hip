@@ -39,7 +39,7 @@ int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
-extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc;
+extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks;
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
@@ -66,6 +66,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 24) { g_conv_gemm_minc = value; return 0; }
     if (id == 25) { g_wgrad_gemm = value; return 0; }
     if (id == 26) { g_wgrad_gemm_minc = value; return 0; }
+    if (id == 27) { g_bnred_blocks = value > 0 ? value : 1024; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }

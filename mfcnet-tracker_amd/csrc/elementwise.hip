@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
     }
 }
 
+int g_bnred_blocks = 1024;           // workgroups of a BN-backward reduce launch; tuning: mfc_set_flag(27, n)
 static int bnbwd_check(const mfc_bnbwd_desc* d, int& E) {
     if (!d || (d->dtype != MFC_F32 && d->dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
     E = d->dtype == MFC_BF16 ? 8 : 4;
@@ -337,7 +338,7 @@ extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
     const int PPI = 256 / Cg;
     const int G = d->N / d->images_per_group;
     const long ppg = (long)d->images_per_group * d->y.H * d->y.W;
-    long want = ppg / (8L * PPI) + 1; if (want > 1024 / G + 1) want = 1024 / G + 1;   // blocks per group (~1024 in total, >= 8 pixels per thread)
+    long want = ppg / (8L * PPI) + 1; if (want > g_bnred_blocks / G + 1) want = g_bnred_blocks / G + 1;   // blocks per group (~1024 in total, >= 8 pixels per thread)
     int ppb = (int)((ppg + want - 1) / want);
     ppb = ((ppb + PPI - 1) / PPI) * PPI;
     const int bx = (int)((ppg + ppb - 1) / ppb);
