@@ -153,7 +153,8 @@ def main():
     opt = mfc.FlatAdam(model, lr=1e-4)
     frames, mask, depth, flow = synth(B, T, H, W, nc, 42 + 2000 + rank, device, args.depth, args.optflow)
 
-    reducer = GradBucketReducer(model, average=False) if world > 1 else None
+    # (MFC_FORCE_BUCKETS: run the segmented backward + bucket hook on one GPU too, to measure what the segmentation costs)
+    reducer = GradBucketReducer(model, average=False) if (world > 1 or os.environ.get("MFC_FORCE_BUCKETS")) else None
 
     def fwd():
         return model(frames[0]) if args.single else model(frames, optflow=flow, depth=depth)

@@ -383,6 +383,10 @@ int mfc_program_run(const mfc_op* ops, int32_t n, void* stream);
  * stream; section lanes / detached records become parallel graph branches), replay with mfc_graph_launch.  All pointers in
  * the records are baked into the graph, which is what the static plan guarantees.  Measured on MI355X / ROCm 7.2: no faster
  * than mfc_program_run (the step is GPU-bound and the host already runs ahead), so the Python layer does not use it. */
+/* Backward segments (data parallel): with mfc_set_flag(28, 1) a program does not join the detached stream at its end -- the next
+ * program of the step continues on it and the last one joins everything.  mfc_wait_detached makes `stream` wait for the detached
+ * records issued so far (e.g. the stream an all-reduce of freshly unpacked gradients is ordered after). */
+int mfc_wait_detached(void* stream);
 int mfc_graph_capture(const mfc_op* ops, int32_t n, void* stream, void** exec_out);
 int mfc_graph_launch(void* exec, void* stream);
 int mfc_graph_destroy(void* exec);
@@ -419,7 +423,8 @@ int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded eve
  *  23  conv: big 1x1 / stride-1 convolutions without input transform run as a plain GEMM (conv_gemm1x1.hip) (1)
  *  24  conv: smallest Cin and Cout sent to that GEMM (128)
  *  25  wgrad: 1x1 weight gradients without input transform as a split-K GEMM (wgrad_gemm1x1.hip) (1)
- *  26  wgrad: smallest Cin and Cout sent to that GEMM (64)           27  BN-backward reduce: workgroups per launch (1024; 512-2048 measured equal) */
+ *  26  wgrad: smallest Cin and Cout sent to that GEMM (64)           27  BN-backward reduce: workgroups per launch (1024; 512-2048 measured equal)
+ *  28  program: defer the final join of the detached stream to the next program (0; set by the segmented backward) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

@@ -31,6 +31,7 @@ int mfc_conv_set_lds_kb(int v);
 int mfc_conv_set_ybfast(int v);
 int mfc_set_lanes(int on);
 int mfc_set_probe_streams(int v);
+int mfc_set_defer_join(int v);
 int mfc_set_async_streams(int n);
 int mfc_set_lane_streams(int n);
 int mfc_set_async_on_lane(int k);
@@ -67,6 +68,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 25) { g_wgrad_gemm = value; return 0; }
     if (id == 26) { g_wgrad_gemm_minc = value; return 0; }
     if (id == 27) { g_bnred_blocks = value > 0 ? value : 1024; return 0; }
+    if (id == 28) return mfc_set_defer_join(value);
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }

@@ -289,6 +289,8 @@ static int run_one(const mfc_op& o, void* stream) {
 struct LaneSet {
     hipStream_t m, s[MFC_MAX_LANES + 1]; hipEvent_t enter, leave, fork, join[MFC_MAX_LANES + 1];
     hipStream_t as[MFC_ASYNC_STREAMS]; hipEvent_t aev[MFC_ASYNC_EVENTS], ajoin[MFC_ASYNC_STREAMS];
+    hipEvent_t seg;          // recorded on the detached stream at the end of a program whose final join was deferred (mfc_wait_detached)
+    bool pending;            // detached work of an earlier program has not been joined yet
     bool ready;
 };
 static LaneSet g_lanes[16];
@@ -309,6 +311,8 @@ int mfc_set_lanes(int on) { g_lanes_on = on; return 0; }
 static int g_async_prio = 0;     // priority of the detached stream: 1 lowest, 0 default, -1 highest (read when the streams are created).  Measured:
                                  // either non-default priority costs 35 % of the step (526 -> 330 frames/s) -- keep 0; mfc_set_flag(16, v)
 int mfc_set_async_prio(int v) { g_async_prio = v; return 0; }
+static int g_defer_join = 0;     // 1: a program does not join the detached stream at its end (the next program of the step will); mfc_set_flag(28, v)
+int mfc_set_defer_join(int v) { g_defer_join = v; return 0; }
 static int g_skip_kinds = 0;     // tuning only: bit k set -> records of kind k are skipped (what-if timing); mfc_set_flag(15, mask)
 int mfc_set_skip_kinds(int m) { g_skip_kinds = m; return 0; }
 static int g_async_on_lane = 0;  // 0: detached records on their own stream; k >= 2: on side lane k's stream; tuning: mfc_set_flag(13, k)
@@ -372,6 +376,8 @@ static LaneSet* lanes_for_device(hipStream_t caller = nullptr, bool may_probe = 
             if (hipEventCreateWithFlags(&L->join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         for (int i = 0; i < MFC_ASYNC_STREAMS; ++i)
             if (hipEventCreateWithFlags(&L->ajoin[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&L->seg, hipEventDisableTiming) != hipSuccess) return nullptr;
+        L->pending = false;
         for (int i = 0; i < MFC_ASYNC_EVENTS; ++i)
             if (hipEventCreateWithFlags(&L->aev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (may_probe && g_probe_streams && g_async_prio == 0) {
@@ -413,7 +419,8 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
     hipStream_t mainst = (multi && !g_capturing && g_own_main) ? L->m : caller;
     if (mainst != caller) { (void)hipEventRecord(L->enter, caller); (void)hipStreamWaitEvent(mainst, L->enter, 0); }
     bool in_par = false; unsigned used = 0;
-    unsigned aused = 0; int anext = 0, aevn = 0;
+    unsigned aused = (L && L->pending) ? 1u : 0u;     // detached work left over from a program that deferred its join: same stream, in order
+    int anext = 0, aevn = 0;
     auto join = [&]() {
         for (int l = 2; l <= MFC_MAX_LANES; ++l)
             if (used & (1u << l)) { (void)hipEventRecord(L->join[l], L->s[l]); (void)hipStreamWaitEvent(mainst, L->join[l], 0); }
@@ -461,9 +468,28 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
         if (rc != MFC_OK) { if (in_par) join(); if (aused) join_async(); leave(); return -(1000 * (i + 1)) + rc; }
     }
     if (in_par) join();
-    if (aused) join_async();
+    const bool can_defer = g_defer_join && !g_capturing && g_async_n == 1 && !(g_async_on_lane >= 2 && g_async_on_lane <= MFC_MAX_LANES);
+    if (aused && can_defer) {
+        // the caller continues with another program of the same step (backward segments): the detached stream is NOT joined here; an
+        // event marks this point on it, for whoever needs the detached results so far (mfc_wait_detached), and the next program's
+        // final join covers everything (one stream, in order)
+        (void)hipEventRecord(L->seg, L->as[0]);
+        L->pending = true;
+    } else if (aused) {
+        join_async();
+        if (L) L->pending = false;
+    }
     leave();
     return MFC_OK;
+}
+
+// Make `stream` wait for the detached records issued so far by programs that deferred their final join (mfc_set_flag(28, 1)).
+extern "C" int mfc_wait_detached(void* stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return MFC_ERR_LAUNCH;
+    LaneSet* L = &g_lanes[dev];
+    if (!L->ready || !L->pending) return MFC_OK;       // nothing outstanding
+    return hipStreamWaitEvent((hipStream_t)stream, L->seg, 0) == hipSuccess ? MFC_OK : MFC_ERR_LAUNCH;
 }
 
 // hipGraph capture of a whole program (lanes become parallel graph branches).  `stream` must not be the null stream.

@@ -67,6 +67,7 @@ class GradBucketReducer:
     def __init__(self, model, average=True, group=None):
         self.model, self.average, self.group = model, average, group
         self.works, self.ranges = [], []
+        self._comm = None
         model.grad_bucket_hook = self._on_bucket
 
     def _on_bucket(self, lo, hi):
@@ -75,8 +76,22 @@ class GradBucketReducer:
             return
         sl = self.model._G[lo:hi]
         avg = self.average and dist.get_backend(self.group) == "nccl"
-        self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True),
-                           sl, self.average and not avg))
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        if sl.is_cuda:
+            # the bucket's weight gradients are summed by an unpack launch on the interpreter's detached stream, which the backward
+            # chain does not wait for: order a side stream after (1) the chain so far and (2) that detached work, and issue the
+            # collective from it (the process group orders its own stream after the stream the call is made on)
+            from . import _lib as L
+            import ctypes as C
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            self._comm.wait_stream(torch.cuda.current_stream())
+            L.check(L.lib.mfc_wait_detached(C.c_void_p(self._comm.cuda_stream)), "mfc_wait_detached")
+            with torch.cuda.stream(self._comm):
+                work = dist.all_reduce(sl, op=op, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(sl, op=op, group=self.group, async_op=True)
+        self.works.append((work, sl, self.average and not avg))
 
     def finish(self):
         ws = dist.get_world_size(self.group) if dist.is_initialized() else 1

@@ -745,7 +745,7 @@ class Plan:
                 self._unpack_devs.append(dev)
                 r = L.RawOp(dev.data_ptr(), 0, 0, 0)
                 r.i[0:2] = [nup, nbu]
-                recs.append((L.OP_UNPACK, r))
+                recs.append((L.OP_UNPACK, r, L.LANE_ASYNC if self.lanes else 0))      # behind its weight gradients on the detached stream
             if rank == 0:
                 recs = pro + recs
             self.bwd_segments.append((self._program(recs), bk["lo"], bk["hi"]))
@@ -816,9 +816,21 @@ class Plan:
             if rc != 0:
                 raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
             return
-        for prog, lo, hi in self.bwd_segments:
-            rc = L.lib.mfc_program_run(prog, len(prog), L.stream_ptr())
+        nseg = len(self.bwd_segments)
+        for i, (prog, lo, hi) in enumerate(self.bwd_segments):
+            # every segment but the last leaves the detached stream un-joined (the chain does not wait for the weight gradients of the
+            # segment); the bucket's consumer orders itself after them with mfc_wait_detached
+            defer = self.lanes and i + 1 < nseg
+            if defer:
+                L.lib.mfc_set_flag(28, 1)
+            try:
+                rc = L.lib.mfc_program_run(prog, len(prog), L.stream_ptr())
+            finally:
+                if defer:
+                    L.lib.mfc_set_flag(28, 0)
             if rc != 0:
                 raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
             if hook is not None:
-                hook(lo, hi)            # gradients [lo, hi) of the flat arena are final once the stream reaches this point
+                # gradients [lo, hi) of the flat arena are final for a stream that (1) waits for the current stream and (2) has called
+                # mfc_wait_detached -- dist.GradBucketReducer does both for the stream the all-reduce is ordered after
+                hook(lo, hi)

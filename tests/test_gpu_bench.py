@@ -53,3 +53,14 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 4 * 3 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]
     assert 0.0 < d["config"]["final_loss"] < 20.0
+
+
+def test_overlapped_bucket_allreduce_equals_the_plain_order():
+    """Two gloo ranks on the one GPU: gradients with the per-bucket all-reduces started inside the segmented backward (detached
+    unpacks, mfc_wait_detached) against whole-backward-then-all-reduce (tests/dist_overlap_check.py)."""
+    _need_gpu()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(ROOT, "tests", "dist_overlap_check.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "OVERLAP_CHECK ok=1" in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])

@@ -404,8 +404,9 @@ def test_ragged_shapes_vs_oracle(mfc, T, B, H, W):
 
 def test_bucketed_backward_hook_covers_the_arena(mfc):
     """The backward pass runs as segments that finalise the flat gradient arena bucket by bucket (plan.py::_build_grad_buckets);
-    the hook a data-parallel run uses to start its per-bucket all-reduces sees ranges that tile the arena, and at every call the
-    gradients of that range already hold their final values (checked against the same backward without a hook)."""
+    the hook a data-parallel run uses to start its per-bucket all-reduces sees ranges that tile the arena, and a stream ordered after
+    the chain and the detached stream (mfc_wait_detached) reads the final values of that range (checked against the same backward
+    without a hook)."""
     cfg, z = load_case("large_rgb_train")
     frames, flows, depths, mask = case_inputs(cfg)
     m = build(mfc, cfg)
@@ -417,9 +418,18 @@ def test_bucketed_backward_hook_covers_the_arena(mfc):
     ref = m._G.detach().clone()
     seen, snaps = [], []
 
+    import ctypes as C
+    from mfcnet_amd import _lib as L
+    side = torch.cuda.Stream()
+
     def hook(lo, hi):
+        # what dist.GradBucketReducer does: a side stream ordered after the chain so far AND after the detached stream (the segment's
+        # unpack runs there; the chain itself no longer waits for it) reads the bucket
         seen.append((lo, hi))
-        snaps.append((lo, hi, m._G[lo:hi].detach().clone()))        # (a copy on the same stream: ordered after the segment)
+        side.wait_stream(torch.cuda.current_stream())
+        assert L.lib.mfc_wait_detached(C.c_void_p(side.cuda_stream)) == 0
+        with torch.cuda.stream(side):
+            snaps.append((lo, hi, m._G[lo:hi].detach().clone()))
 
     m.grad_bucket_hook = hook
     for prm in m.parameters():
