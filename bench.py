@@ -82,8 +82,8 @@ def cpu_baseline(width, T, H, W, steps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=32, help="HRNet width: 32 = BASELINE.json metric label, 48 = reference")
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=3)
