@@ -7,9 +7,10 @@
 // 96-channel block.  A 1x1 / stride-1 convolution has no halo, so here it runs as Y[M][Cout] = X[M][Cin] . W^T:
 //   * workgroup = 8 waves, tile 256 pixels x 256 output channels, K chunks of 64 channels; wave (wm, wn) owns 128 pixels x 64
 //     channels = 8 x 4 MFMA tiles (v_mfma_f32_16x16x32_bf16): 32 MFMAs per 12 fragment reads;
-//   * both operands go global -> LDS by DMA (global_load_lds_dwordx4), double buffered, no registers in the staging path: the
+//   * both operands go global -> LDS by DMA (global_load_lds_dwordx4), no registers in the staging path; a pipeline stage is one
+//     k-step (32 channels: 16 KiB + 16 KiB) and four stages are resident, so the DMA runs three stages ahead of the MFMAs; the
 //     weights are the packed image of mfc_pack_weights ([chunk][cout block][granule][256 couts], one 32 KiB stage = one LDS
-//     image), the activations land as [pixel][granule ^ (pixel & 7)] (XOR swizzle: the DMA writes lane-contiguous LDS, so the
+//     image, its halves one stage each), the activations land as [pixel][granule ^ ((pixel >> 1) & 3)] in 64-byte rows (XOR swizzle: the DMA writes lane-contiguous LDS, so the
 //     swizzle is applied to the SOURCE granule each lane fetches -- free), which makes the fragment reads conflict free;
 //   * persistent workgroups over contiguous pixel-tile ranges; the input is read once per 256-channel block;
 //   * the fused input transform (BatchNorm + ReLU of the producer) is applied to the activation tile in place in LDS after it landed;
@@ -35,15 +36,21 @@ __device__ inline float g_row16_sum(float v) {      // sum over the 16 lanes of 
     return v;
 }
 
-constexpr int G_BM = 256, G_BN = 256, G_KG = 8;                 // pixels, couts, granules (of 8 channels) per stage
-constexpr int G_ABYTES = G_BM * G_KG * 16, G_BBYTES = G_KG * G_BN * 16;      // 32 KiB each
-constexpr int G_OFF_A0 = 0, G_OFF_A1 = G_ABYTES, G_OFF_B0 = 2 * G_ABYTES, G_OFF_B1 = 2 * G_ABYTES + G_BBYTES;
+constexpr int G_BM = 256, G_BN = 256, G_KG = 8;                 // pixels, couts per tile; granules (of 8 channels) per packed weight chunk
+constexpr int G_BBYTES = G_KG * G_BN * 16;                       // one packed weight chunk image: 32 KiB
+// a pipeline stage is HALF a chunk (4 granules = 32 channels = one MFMA k-step): 16 KiB of activations + 16 KiB of weights, and FOUR
+// stages are resident, so the DMA of stage s+3 is issued while stage s computes (one DMA round trip is ~3 us, a k-step 0.4 us)
+constexpr int G_HG = 4, G_NBUF = 4;
+constexpr int G_AH = G_BM * G_HG * 16, G_BH = G_HG * G_BN * 16;  // 16 KiB each
+constexpr int G_OFF_A = 0, G_OFF_B = G_NBUF * G_AH;
 constexpr int G_MAXYB = 4;                                       // cout blocks whose statistics are kept in LDS side by side
 constexpr int G_RED1 = 8 * 2 * 64;                               // floats of one block's sums: [8 waves][2][64]
-constexpr int G_OFF_RED = 2 * G_ABYTES + 2 * G_BBYTES;        // float [G_MAXYB][8 waves][2][64]
+constexpr int G_OFF_RED = G_NBUF * (G_AH + G_BH);                // float [G_MAXYB][8 waves][2][64]
 constexpr int G_OFF_COEF = G_OFF_RED + G_MAXYB * G_RED1 * 4;     // float [G][2][Cin_p]: scale / shift of the fused input transform
 constexpr int G_COEF_FLOATS = 3072;
-constexpr int G_LDS = G_OFF_COEF + G_COEF_FLOATS * 4;
+constexpr int G_OFF_BIAS = G_OFF_COEF + G_COEF_FLOATS * 4;       // float [Cout <= 1024] (LDS: an epilogue load from global would drain the DMA pipeline)
+constexpr int G_BIAS_FLOATS = 1024;
+constexpr int G_LDS = G_OFF_BIAS + G_BIAS_FLOATS * 4;            // = 160 KiB
 
 __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
     // up to G_MAXYB blocks are kept side by side in LDS across tiles; with more blocks the order flips (block slowest)
     const bool ybfast = (p.out_stats == nullptr) || p.Yblocks <= G_MAXYB;
     const int nunits = ntl * p.Yblocks;
-    const int S = nunits * p.nchunks;
+    const int T = nunits * p.nchunks * 2;                    // pipeline stages (half chunks)
     const int cq = (lane >> 4) * 4;
 
     auto unit_of = [&](int u, int& t, int& yb) {
@@ -74,38 +81,51 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
     };
-    auto dma_stage = [&](int t, int c, int yb, int par) {
-        const unsigned la = lds0 + (par ? G_OFF_A1 : G_OFF_A0), lb = lds0 + (par ? G_OFF_B1 : G_OFF_B0);
-        const char* wsrc = p.wp + (size_t)(c * p.Yblocks + yb) * G_BBYTES + lane * 16;
+    auto dma_stage = [&](int t, int c, int h, int yb, int buf) {
+        const unsigned la = lds0 + G_OFF_A + buf * G_AH, lb = lds0 + G_OFF_B + buf * G_BH;
+        const char* wsrc = p.wp + (size_t)(c * p.Yblocks + yb) * G_BBYTES + h * G_BH + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = wave * 4 + i;                     // 1-KiB piece: pixels q*8 .. q*8+7, all 8 granule slots
-            const int pl = q * 8 + (lane >> 3);
-            const int gi = min(c * G_KG + ((lane & 7) ^ (pl & 7)), p.Cin_g - 1);      // (tail chunk: a valid granule; its weights are zero)
+        for (int i = 0; i < 2; ++i) {
+            const int q = wave * 2 + i;                     // 1-KiB piece: pixels q*16 .. q*16+15, the 4 granule slots of the half chunk
+            const int pl = q * 16 + (lane >> 2);
+            const int gi = min(c * G_KG + h * G_HG + ((lane & 3) ^ ((pl >> 1) & 3)), p.Cin_g - 1);      // (tail: a valid granule; its weights are zero)
             dma1k(p.in + ((size_t)t * G_BM + pl) * p.Cin_p * 2 + (size_t)gi * 16, la + q * 1024);
             dma1k(wsrc + q * 1024, lb + q * 1024);
         }
     };
-    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // wait until at most k later stages (4 DMA instructions per wave and stage) are still in flight
+    auto dma_wait = [&](int k) {
+        if (k >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (k == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
 
     f32x4 acc[8][4];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // fragment addressing: A (pixels) [pl][slot ^ (pl & 7)], pl = wm*128 + mt*16 + (lane & 15); B (couts) [slot][256 couts]
-    const int a_row = (wm * 128 + (lane & 15)) * 128;
-    const int a_k0 = (((lane >> 4)) ^ (lane & 7)) * 16, a_k1 = ((4 + (lane >> 4)) ^ (lane & 7)) * 16;
+    // fragment addressing: A (pixels) [pl][slot ^ ((pl >> 1) & 3)] with 64-byte rows, pl = wm*128 + mt*16 + (lane & 15); B (couts) [slot][256 couts]
+    const int a_off = (wm * 128 + (lane & 15)) * 64 + (((lane >> 4) ^ (((lane & 15) >> 1) & 3)) * 16);
     const int b_off = ((lane >> 4) * G_BN + wn * 64 + (lane & 15)) * 16;
 
     for (int i = tid; i < G_MAXYB * G_RED1; i += 512) red[i] = 0.f;
+    float* biasl = (float*)(smem + G_OFF_BIAS);
+    for (int i = tid; i < G_BIAS_FLOATS; i += 512) biasl[i] = (p.bias && i < p.Cout) ? p.bias[i] : 0.f;
     int t, yb;
     unit_of(0, t, yb);
-    dma_stage(t, 0, yb, 0);
-    dma_wait();
+    // issue cursor: runs G_NBUF-1 stages ahead of the compute cursor
+    int iu = 0, ic = 0, ih = 0, it = t, iyb = yb, issued = 0;
+    auto issue_next = [&]() {
+        dma_stage(it, ic, ih, iyb, issued & (G_NBUF - 1));
+        ++issued;
+        if (++ih == 2) { ih = 0; if (++ic == p.nchunks) { ic = 0; ++iu; if (iu < nunits) unit_of(iu, it, iyb); } }
+    };
+    for (int k = 0; k < G_NBUF - 1 && issued < T; ++k) issue_next();
+    dma_wait(issued - 1);
     __syncthreads();
 
-    int u = 0, c = 0;
+    int u = 0, c = 0, h = 0;
     int red_grp = -1, red_yb = -1; bool red_live = false;
     auto stats_flush = [&]() {          // every wave has added its row sums to red[yb][wave]; sum the two pixel halves, publish, clear
         __syncthreads();
@@ -134,13 +154,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
         }
         __syncthreads();
     }
-    auto transform = [&](int par, int tt, int cc) {
-        char* At = smem + (par ? G_OFF_A1 : G_OFF_A0);
+    auto transform = [&](int buf, int tt, int cc, int hh) {
+        char* At = smem + G_OFF_A + buf * G_AH;
         const float* sc = cfl + (size_t)(((long)tt * G_BM) / p.px_per_group) * 2 * p.Cin_p;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = tid + k * 512;                      // granule slot: pixel idx >> 3, position idx & 7
-            const int pl = idx >> 3, cg = cc * G_KG + ((idx & 7) ^ (pl & 7));
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + k * 512;                      // granule slot: pixel idx >> 2, position idx & 3
+            const int pl = idx >> 2, cg = cc * G_KG + hh * G_HG + ((idx & 3) ^ ((pl >> 1) & 3));
             if (cg < p.Cin_g) {
                 float f[8];
                 Gran<bf16_t>::unpack(*(const uint4*)(At + idx * 16), f);
@@ -157,39 +177,34 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
         }
     };
 
-    for (int s = 0; s < S; ++s) {
-        // next stage coordinates
-        int u2 = u, c2 = c + 1, t2 = t, yb2 = yb;
-        if (c2 == p.nchunks) { c2 = 0; ++u2; if (u2 < nunits) unit_of(u2, t2, yb2); }
-        if (s + 1 < S) dma_stage(t2, c2, yb2, (s + 1) & 1);
-        if (p.in_coef) { transform(s & 1, t, c); __syncthreads(); }
+    for (int s = 0; s < T; ++s) {
+        if (issued < T) issue_next();                       // stage s + 3 into the buffer stage s - 1 has just left
+        const int buf = s & (G_NBUF - 1);
+        if (p.in_coef) { transform(buf, t, c, h); __syncthreads(); }
 
-        // ---------------- compute: 2 k-steps of 32 channels ----------------
-        const char* A = smem + ((s & 1) ? G_OFF_A1 : G_OFF_A0) + a_row;
-        const char* B = smem + ((s & 1) ? G_OFF_B1 : G_OFF_B0) + b_off;
+        // ---------------- compute: one k-step of 32 channels ----------------
+        const char* A = smem + G_OFF_A + buf * G_AH + a_off;
+        const char* B = smem + G_OFF_B + buf * G_BH + b_off;
         const int n0 = yb * G_BN + wn * 64;
         const int ntv = min(4, (p.Cout - n0 + 15) >> 4);         // cout tiles of this wave that hold real channels (wave-uniform)
         if (ntv > 0) {
+            bf16x8 x[8], w[4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 x[8], w[4];
+            for (int mt = 0; mt < 8; ++mt) x[mt] = *(const bf16x8*)(A + mt * 16 * 64);
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) x[mt] = *(const bf16x8*)(A + mt * 16 * 128 + (ks ? a_k1 : a_k0));
+            for (int nt = 0; nt < 4; ++nt) w[nt] = *(const bf16x8*)(B + nt * 256);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) w[nt] = *(const bf16x8*)(B + ks * 4 * G_BN * 16 + nt * 256);
+            for (int nt = 0; nt < 4; ++nt)
+                if (nt < ntv) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    if (nt < ntv) {
-#pragma unroll
-                        for (int mt = 0; mt < 8; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], x[mt], acc[mt][nt], 0, 0, 0);
-                    }
-            }
+                    for (int mt = 0; mt < 8; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], x[mt], acc[mt][nt], 0, 0, 0);
+                }
         }
-        // the DMA of the next stage has landed (this wave's pieces), then everybody's; the other buffer may be overwritten next round
-        dma_wait();
+        // stage s + 1 has landed (this wave's pieces; the later ones may still be in flight), then everybody's
+        dma_wait(issued - s - 2);
         __syncthreads();
 
-        if (c == p.nchunks - 1) {
+        if (h == 1 && c == p.nchunks - 1) {
             // ---------------- epilogue of unit (t, yb) ----------------
             const int grp = p.out_stats ? (int)(((long)t * G_BM) / p.px_per_group) : 0;
             if (p.out_stats && red_live && (grp != red_grp || (!ybfast && yb != red_yb))) stats_flush();
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = n0 + nt * 16 + cq + r;
-                    bq[nt][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+                    bq[nt][r] = biasl[min(co, G_BIAS_FLOATS - 1)];          // (zero beyond Cout)
                 }
             float ssum[4][4], ssq[4][4];
 #pragma unroll
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
                 red_live = true; red_grp = grp; red_yb = yb;
             }
         }
-        u = u2; c = c2; t = t2; yb = yb2;
+        if (++h == 2) { h = 0; if (++c == p.nchunks) { c = 0; ++u; if (u < nunits) unit_of(u, t, yb); } }
     }
     if (p.out_stats && red_live) stats_flush();
 }
@@ -290,7 +305,7 @@ bool gemm1x1_eligible(const mfc_conv_desc* d) {
     if (d->TA != 1 || d->TB != 1 || d->in_stride != 1 || d->dh0 != 0 || d->dw0 != 0) return false;
     if (d->out_sh != 1 || d->out_sw != 1 || d->out_oh != 0 || d->out_ow != 0) return false;
     if (d->Hl != d->Hout || d->Wl != d->Wout || d->Hin != d->Hout || d->Win != d->Wout) return false;
-    if (d->Cin_p % 8 || d->Cout_p % 8) return false;
+    if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cout > G_BIAS_FLOATS) return false;
     // wide enough for the 256-channel tile: >= 128 channels on both sides, or a full 256-channel block from >= 64 (measured:
     // 64 -> 256 at 120x160: 93 -> 74 us; 64 -> 128: 45 -> 49 us; 256 -> 64: 66 -> 94 us)
     if (!((d->Cin >= g_conv_gemm_minc && d->Cout >= g_conv_gemm_minc) || (d->Cin >= 64 && d->Cout >= 256))) return false;
