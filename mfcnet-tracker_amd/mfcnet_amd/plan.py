@@ -251,7 +251,7 @@ class Plan:
 
     # ------------------------------------------------------------------ weight-gradient launches
     def _queue_wgrad(self, ci: ConvInfo):
-        """Weight gradients are detached work (nothing reads them before the final unpack), so those of identical geometry are
+        """Weight gradients are detached work (nothing reads them before their unpack, which runs behind them on the same stream), so those of identical geometry are
         collected and launched together, up to 8 per launch (mfc_conv2d_wgrad_batch): the 8 3x3 convolutions of a module
         branch become ONE launch whose workgroups each walk 8x more pixels of one problem."""
         w = ci.wg
@@ -292,7 +292,7 @@ class Plan:
                     r = L.RawOp(C.addressof(arr), 0, 0, 0)
                     r.i[0] = m
                     self.bwd.append((L.OP_WGRAD_BATCH, r))
-                if self.lanes:      # detached: nothing reads the partial sums before the final unpack
+                if self.lanes:      # detached: nothing reads the partial sums before their unpack (same stream, in order)
                     k_, d_, ln_ = self.bwd[-1]
                     self.bwd[-1] = (k_, d_, ln_ | L.LANE_ASYNC)
                 for ci in grp:
@@ -751,8 +751,7 @@ class Plan:
             self.bwd_segments.append((self._program(recs), bk["lo"], bk["hi"]))
             start = end
         assert start == last + 1
-        # the same backward as ONE program with a single final unpack: what a run without a bucket hook executes (the segment
-        # ends join the detached weight-gradient stream, which costs ~2 % of a single-GPU step)
+        # the same backward as ONE program: what a run without a bucket hook executes.
         # Its unpack work is cut into chunks that follow their weight-gradient launches ON THE DETACHED STREAM (same stream, in order, so
         # no event is needed): the slices of the first layers of the backward are summed while the chain is still running, and
         # only the last chunk is left when the chain ends (one final unpack used to add 0.5 ms after the join).
