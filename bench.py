@@ -148,6 +148,8 @@ def main():
                     optflow_inputs=args.optflow, depth_inputs=args.depth)
     model = model.to(device)
     model = model.eval() if args.fwd_only else model.train()
+    if os.environ.get("MFC_MASK_BITS"):            # tuning: 0 = the BatchNorm backward reads the ReLU mask from the bf16 tensor
+        model.relu_mask_bits = os.environ["MFC_MASK_BITS"] != "0"
     if os.environ.get("MFC_BATCH_WGRAD"):          # tuning: 0 = one launch per weight gradient
         model.batch_wgrad = os.environ["MFC_BATCH_WGRAD"] != "0"
     opt = mfc.FlatAdam(model, lr=1e-4)

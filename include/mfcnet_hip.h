@@ -208,6 +208,8 @@ typedef struct {
     int32_t nsrc, relu, dtype;
     int32_t N, C;            /* C: channels in the slice (multiple of granule size or padded) */
     int32_t images_per_group;
+    uint64_t maskbits;       /* optional (bf16): uint8 [N*H*W*out.Cp/8], bit e of byte (pixel*Cp + c)/8 = out[pixel][c + e] > 0 -- the
+                              * ReLU mask the BatchNorm backward of the summed terms reads (mask_mode 3) instead of the whole tensor */
 } mfc_combine_desc;
 int mfc_combine_fwd(const mfc_combine_desc* d, void* stream);
 
@@ -226,7 +228,7 @@ int mfc_combine_fwd(const mfc_combine_desc* d, void* stream);
 typedef struct {
     mfc_view g;              /* gradient wrt the BN output (post-activation if mask) */
     mfc_view y;              /* conv output (pre-BN); y.coef = this BN's coefficient block */
-    mfc_view mask;           /* mode 1: tensor whose sign gives the ReLU mask */
+    mfc_view mask;           /* mode 1: tensor whose sign gives the ReLU mask; mode 3 (bf16): its 1-bit image written by mfc_combine_fwd (ptr = bits) */
     mfc_view dy;             /* apply: destination (may alias g); reduce: optional g*m output */
     float* bstats;           /* [R][G][2][Cp] */
     const float* bcoef;      /* [G][2][Cp] c1, c2 (apply) */

@@ -147,6 +147,14 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, lo
         for (int e = 0; e < E; ++e) acc[e] = relu_nan(acc[e]);
     }
     *(uint4*)((char*)d.out.ptr + ((((size_t)n * d.out.H + h) * d.out.W + w) * d.out.Cp + d.out.c_off + g * E) * sizeof(T)) = Gran<T>::pack(acc);
+    if constexpr (E == 8) {
+        if (d.maskbits) {
+            unsigned b = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b |= (acc[e] > 0.f ? 1u : 0u) << e;
+            ((unsigned char*)d.maskbits)[((((size_t)n * d.out.H + h) * d.out.W + w) * d.out.Cp + d.out.c_off + g * E) >> 3] = (unsigned char)b;
+        }
+    }
 }
 
 // all sources at the output resolution (residual blocks, BN materialisation): linear pixel index, 2 granules per thread
@@ -192,6 +200,14 @@ __global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, l
             for (int e = 0; e < E; ++e) acc[e] = relu_nan(acc[e]);
         }
         *(uint4*)((char*)d.out.ptr + ((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(acc);
+        if constexpr (E == 8) {
+            if (d.maskbits) {       // the ReLU mask of the backward pass: one bit per element
+                unsigned b = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b |= (acc[e] > 0.f ? 1u : 0u) << e;
+                ((unsigned char*)d.maskbits)[((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) >> 3] = (unsigned char)b;
+            }
+        }
     }
 }
 
@@ -243,8 +259,13 @@ __device__ inline void apply_mask(const mfc_bnbwd_desc& d, const uint4& mraw, co
     } else if (d.mask_mode == 2) {
 #pragma unroll
         for (int e = 0; e < E; ++e) gm[e] = (yv[e] * cf[e] + cf[d.y.Cp + e]) > 0.f ? gm[e] : 0.f;
+    } else if (d.mask_mode == 3) {          // one bit per element, one byte per 8-channel granule (written by mfc_combine_fwd)
+#pragma unroll
+        for (int e = 0; e < E; ++e) gm[e] = ((mraw.x >> e) & 1u) ? gm[e] : 0.f;
     }
 }
+// the byte of mask bits of granule (pixel, channel c) of a [.., Cp] tensor
+__device__ inline unsigned ld_bits(const mfc_view& v, long pix, int c) { return ((const unsigned char*)v.ptr)[((size_t)pix * v.Cp + c) >> 3]; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int Cg, int PPI, int pix_per_block, long pix_per_group) {
@@ -273,6 +294,7 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
             yr[u] = ld_lin<T>(d.y, gbase + qq, ych);
             gr[u] = ld_lin<T>(d.g, gbase + qq, gch);
             if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, gbase + qq, mch);
+            else if (d.mask_mode == 3) mr[u].x = ld_bits(d.mask, gbase + qq, mch);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -324,7 +346,8 @@ static int bnbwd_check(const mfc_bnbwd_desc* d, int& E) {
     if (!view_ok(d->g, E) || !view_ok(d->y, E) || !d->y.coef || d->C <= 0 || d->C % E) return MFC_ERR_INVALID_ARG;
     if (d->g.H != d->y.H || d->g.W != d->y.W) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode == 1 && (!view_ok(d->mask, E) || d->mask.H != d->y.H || d->mask.W != d->y.W)) return MFC_ERR_INVALID_ARG;
-    if (d->mask_mode < 0 || d->mask_mode > 2) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode < 0 || d->mask_mode > 3) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode == 3 && (d->dtype != MFC_BF16 || !d->mask.ptr || d->mask.Cp % 8 || d->mask.c_off % 8 || d->mask.H != d->y.H || d->mask.W != d->y.W)) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
     return MFC_OK;
 }
@@ -397,6 +420,7 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long
         yr[u] = ld_lin<T>(d.y, pix[u], d.y.c_off + gq[u] * E);
         gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
         if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
+        else if (d.mask_mode == 3) mr[u].x = ld_bits(d.mask, pix[u], d.mask.c_off + gq[u] * E);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -458,6 +482,7 @@ __global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, 
             yr[u] = ld_lin<T>(d.y, pix[u], d.y.c_off + gq[u] * E);
             gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
             if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
+            else if (d.mask_mode == 3) mr[u].x = ld_bits(d.mask, pix[u], d.mask.c_off + gq[u] * E);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

@@ -77,7 +77,7 @@ class View(C.Structure):
 
 class CombineDesc(C.Structure):
     _fields_ = [("out", View), ("src", View * 4), ("nsrc", i32), ("relu", i32), ("dtype", i32),
-                ("N", i32), ("C", i32), ("images_per_group", i32)]
+                ("N", i32), ("C", i32), ("images_per_group", i32), ("maskbits", u64)]
 
 
 class BnBwdDesc(C.Structure):

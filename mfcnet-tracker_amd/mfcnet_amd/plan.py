@@ -61,6 +61,7 @@ class Ten:
     needs_grad: bool = True
     grad: Optional["Ten"] = None
     grad_init: bool = False
+    bits: int = 0                 # 1-bit image of (tensor > 0), written by the ReLU'd combine that produced it (bf16 training)
 
 
 @dataclass
@@ -150,6 +151,7 @@ class Plan:
         # (533 vs 545 frames/s) -- deferring a branch's eight gradients to one launch starves the detached stream -- so off by default
         self.batch_wgrad = getattr(model, "batch_wgrad", False)
         self.fuse_fin = getattr(model, "fuse_bn_finalize", True)     # BN-backward finalize inside the apply launch (C <= 128)
+        self.mask_bits = getattr(model, "relu_mask_bits", True)     # 1-bit ReLU masks for the BatchNorm backward (bf16)
         self.lanes = getattr(model, "parallel_branches", True)      # branch-parallel lanes of the program (include/mfcnet_hip.h, mfc_op.lane)
         self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc")}
         self._build()                       # dry pass: sizes
@@ -347,6 +349,12 @@ class Plan:
         for i, tm in enumerate(terms):
             d.src[i] = self.view(tm.t, tm.bn, tm.c_off)
         d.nsrc, d.relu, d.dtype, d.N, d.C, d.images_per_group = len(terms), 1 if relu else 0, self.dtype, out.N, Cs, out.ipg
+        if relu and self.need_backward and self.dtype == L.BF16 and self.mask_bits and any(tm.bn is not None and tm.t.H == out.H and tm.t.W == out.W for tm in terms):
+            # the BatchNorm backward of the summed terms needs only the sign of this output: keep it as one bit per element
+            # (1/16 of the tensor) so that its reduce pass reads two tensors instead of three
+            if not out.bits:
+                out.bits = self._alloc("act", out.N * out.H * out.W * out.Cp // 8)
+            d.maskbits = out.bits
         self.fwd.append((L.OP_COMBINE, d))
         self.ops.append(("combine", terms, out, out_c_off, Cs, relu))
         return Act(out, None, False)
@@ -577,6 +585,8 @@ class Plan:
                 gv = L.View(g.ptr, 0, g.H, g.W, g.Cp, out_c_off)
                 mv = L.View(out.ptr, 0, out.H, out.W, out.Cp, out_c_off) if relu else None
                 mode = 1 if relu else 0
+                # (same-resolution BatchNorm terms read the 1-bit image of the mask when the forward wrote one)
+                bmode, bmv = (3, L.View(out.bits, 0, out.H, out.W, out.Cp, out_c_off)) if (relu and out.bits) else (mode, mv)
                 same = lambda tm: tm.t.H == out.H and tm.t.W == out.W
                 # The identity term of a ReLU'd sum receives exactly g*m.  If its gradient buffer is still unwritten, let the
                 # BN-backward reduce pass of a same-resolution BN term write it (no separate mask pass), and let every other
@@ -619,10 +629,10 @@ class Plan:
                         if tm is fuse_bn:
                             ig = self.grad_of(idt.t)
                             gmv = L.View(ig.ptr, 0, ig.H, ig.W, ig.Cp, idt.c_off)
-                            self._bn_backward(tm.bn, s, gv, mode, mv, dyv, Cs, gm_view=gmv, gm_acc=0)
+                            self._bn_backward(tm.bn, s, gv, bmode, bmv, dyv, Cs, gm_view=gmv, gm_acc=0)
                             idt.t.grad_init = True
                         else:
-                            self._bn_backward(tm.bn, s, g_in, md_in, m_in, dyv, Cs)
+                            self._bn_backward(tm.bn, s, g_in, *((md_in, m_in) if gmv is not None else (bmode, bmv)), dyv, Cs)
                         s.grad_init = True
             elif kind == "conv":
                 _, x, y, ci, bn = op

@@ -297,6 +297,30 @@ def test_hoisted_eval_bn_finalize_is_bit_identical(mfc):
             assert float((outs[0] - outs[1]).abs().max()) <= ATOL, name
 
 
+def test_one_bit_relu_masks_give_the_same_gradients(mfc):
+    """bf16 training: the ReLU'd sums write a 1-bit image of their output's sign and the BatchNorm backward reads that (mask_mode 3)
+    instead of the whole tensor; same gradients as with the tensor-valued mask (up to the statistic atomics' noise)."""
+    cfg = dict(name="bitscase", model_type="HRNetMulti-Large", T=3, optflow=False, depth=False, B=2, H=96, W=128, mode="train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    res = []
+    for bits in (True, False):
+        m = build(mfc, cfg, dtype="bf16")
+        m.relu_mask_bits = bits
+        m.train()
+        y = m(dev(frames))
+        loss, _ = mfc.mfc_loss(y, mask.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        from mfcnet_amd import _lib as L
+        modes = [op.u.bnbwd.mask_mode for op in next(iter(m._plans.values())).bwd_prog if op.kind == L.OP_BNBWD_REDUCE]
+        assert (3 in modes) == bits and (1 in modes) != bits
+        res.append((y.detach().cpu(), float(loss), m._G.detach().cpu().clone()))
+    (y0, l0, g0), (y1, l1, g1) = res
+    assert torch.equal(y0, y1) or float((y0 - y1).abs().max()) < 0.05 * float(y1.abs().max())
+    assert abs(l0 - l1) < 2e-3
+    assert rel_l2(g0.numpy(), g1.numpy()) < GRAD_RTOL
+
+
 def test_captured_graph_replays_the_forward_program(mfc):
     """mfc_graph_capture / mfc_graph_launch: the forward program as a hipGraph (lanes become graph branches) writes the
     same logits as mfc_program_run."""
