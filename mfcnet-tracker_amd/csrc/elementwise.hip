@@ -595,6 +595,11 @@ __global__ __launch_bounds__(256) void mask_add_kernel(mfc_maskadd_desc d, long 
 #pragma unroll
                     for (int e = 0; e < E; ++e) gv[e] = m[e] > 0.f ? gv[e] : 0.f;
                 }
+                if (d.mask_mode == 3) {
+                    const unsigned mb = ld_bits(d.mask, ((long)n * d.mask.H + hh0 + q) * d.mask.W + ww, d.mask.c_off + g * E);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) gv[e] = ((mb >> e) & 1u) ? gv[e] : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < E; ++e) acc[e] += wt * gv[e];
             }
@@ -647,6 +652,7 @@ __global__ __launch_bounds__(256) void mask_add_wpass_kernel(mfc_maskadd_desc d,
             wt[q] = (ww0 + q <= whi) ? ((w0 == wl ? 1.f - lw : 0.f) + (w1 == wl ? lw : 0.f)) : 0.f;
             gr[q] = *(const uint4*)(grow + (size_t)ww * d.g.Cp * sizeof(T));
             if (d.mask_mode == 1) mr[q] = *(const uint4*)(mrow + (size_t)ww * d.mask.Cp * sizeof(T));
+            else if (d.mask_mode == 3) mr[q].x = ld_bits(d.mask, (long)r * d.mask.W + ww, d.mask.c_off + g * E);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -657,6 +663,10 @@ __global__ __launch_bounds__(256) void mask_add_wpass_kernel(mfc_maskadd_desc d,
                 Gran<T>::unpack(mr[q], m);
 #pragma unroll
                 for (int e = 0; e < E; ++e) gv[e] = m[e] > 0.f ? gv[e] : 0.f;
+            }
+            if (d.mask_mode == 3) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) gv[e] = ((mr[q].x >> e) & 1u) ? gv[e] : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] += wt[q] * gv[e];
@@ -718,6 +728,7 @@ __global__ __launch_bounds__(256) void mask_add_same_kernel(mfc_maskadd_desc d, 
         pix[u] = idx / (unsigned)Cg; gq[u] = (int)(idx - pix[u] * (unsigned)Cg);
         gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
         if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
+        else if (d.mask_mode == 3) mr[u].x = ld_bits(d.mask, pix[u], d.mask.c_off + gq[u] * E);
         if (d.accumulate) dr[u] = ld_lin<T>(d.dst, pix[u], d.dst.c_off + gq[u] * E);
     }
 #pragma unroll
@@ -730,6 +741,10 @@ __global__ __launch_bounds__(256) void mask_add_same_kernel(mfc_maskadd_desc d, 
             Gran<T>::unpack(mr[u], m);
 #pragma unroll
             for (int e = 0; e < E; ++e) gv[e] = m[e] > 0.f ? gv[e] : 0.f;
+        }
+        if (d.mask_mode == 3) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) gv[e] = ((mr[u].x >> e) & 1u) ? gv[e] : 0.f;
         }
         if (d.accumulate) {
             float o[E];
@@ -745,8 +760,9 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
     if (!d || (d->dtype != MFC_F32 && d->dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
     const int E = d->dtype == MFC_BF16 ? 8 : 4;
     if (!view_ok(d->g, E) || !view_ok(d->dst, E) || d->C <= 0 || d->C % E || d->N <= 0) return MFC_ERR_INVALID_ARG;
-    if (d->mask_mode != 0 && d->mask_mode != 1) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode != 0 && d->mask_mode != 1 && d->mask_mode != 3) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode == 1 && (!view_ok(d->mask, E) || d->mask.H != d->g.H || d->mask.W != d->g.W)) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode == 3 && (d->dtype != MFC_BF16 || !d->mask.ptr || d->mask.Cp % 8 || d->mask.c_off % 8 || d->mask.H != d->g.H || d->mask.W != d->g.W)) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     const long total = (long)d->N * d->dst.H * d->dst.W * Cg;
     if (total >= (1L << 31) - 2048 || (long)d->N * d->g.H * d->g.W * Cg >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;

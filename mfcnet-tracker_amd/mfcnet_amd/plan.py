@@ -349,9 +349,9 @@ class Plan:
         for i, tm in enumerate(terms):
             d.src[i] = self.view(tm.t, tm.bn, tm.c_off)
         d.nsrc, d.relu, d.dtype, d.N, d.C, d.images_per_group = len(terms), 1 if relu else 0, self.dtype, out.N, Cs, out.ipg
-        if relu and self.need_backward and self.dtype == L.BF16 and self.mask_bits and any(tm.bn is not None and tm.t.H == out.H and tm.t.W == out.W for tm in terms):
-            # the BatchNorm backward of the summed terms needs only the sign of this output: keep it as one bit per element
-            # (1/16 of the tensor) so that its reduce pass reads two tensors instead of three
+        if relu and self.need_backward and self.dtype == L.BF16 and self.mask_bits:
+            # the backward of the summed terms (BatchNorm reduce, masked adds / up-sampling adjoints) needs only the sign of this
+            # output: keep it as one bit per element (1/16 of the tensor) so that those passes read one tensor less
             if not out.bits:
                 out.bits = self._alloc("act", out.N * out.H * out.W * out.Cp // 8)
             d.maskbits = out.bits
@@ -606,7 +606,7 @@ class Plan:
                     if not s.needs_grad:
                         continue
                     sg = self.grad_of(s)
-                    g_in, m_in, md_in = (gmv, None, 0) if gmv is not None else (gv, mv, mode)
+                    g_in, m_in, md_in = (gmv, None, 0) if gmv is not None else (gv, bmv, bmode)
                     if tm.bn is None or not same(tm):
                         md = L.MaskAddDesc()
                         md.g, md.dst = g_in, L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
@@ -632,7 +632,7 @@ class Plan:
                             self._bn_backward(tm.bn, s, gv, bmode, bmv, dyv, Cs, gm_view=gmv, gm_acc=0)
                             idt.t.grad_init = True
                         else:
-                            self._bn_backward(tm.bn, s, g_in, *((md_in, m_in) if gmv is not None else (bmode, bmv)), dyv, Cs)
+                            self._bn_backward(tm.bn, s, g_in, md_in, m_in, dyv, Cs)
                         s.grad_init = True
             elif kind == "conv":
                 _, x, y, ci, bn = op

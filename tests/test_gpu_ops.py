@@ -38,6 +38,13 @@ def relerr(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+def pack_sign_bits(t_nhwc):
+    """uint8 [N*H*W*Cp/8]: bit e of byte (pixel*Cp + c)/8 = t[pixel][c + e] > 0 (the layout mfc_combine_fwd writes)."""
+    b = (t_nhwc.float() > 0).to(torch.int32).reshape(-1, 8)
+    w = torch.tensor([1 << e for e in range(8)], dtype=torch.int32, device=b.device)
+    return (b * w).sum(1).to(torch.uint8).contiguous()
+
+
 CONV_CASES = [  # N, Cin, Cout, k, s, H, W
     (2, 48, 48, 3, 1, 24, 40), (2, 3, 64, 3, 2, 64, 96), (2, 64, 64, 3, 2, 32, 48), (3, 96, 192, 3, 2, 15, 20),
     (2, 384, 384, 3, 1, 15, 20), (2, 256, 64, 1, 1, 16, 24), (1, 720, 720, 1, 1, 12, 20), (2, 720, 5, 1, 1, 16, 24),
@@ -261,11 +268,16 @@ def test_combine_residual_bilinear(M, dtype):
     d.out = ops.view(out)
     d.src[0], d.src[1], d.src[2], d.src[3] = ops.view(ta), ops.view(tb, cbd), ops.view(tc, ccd), ops.view(te)
     d.nsrc, d.relu, d.dtype, d.N, d.C, d.images_per_group = 4, 1, ops.dt_of(ta), N, Cc, N
+    bits = torch.zeros(out.numel() // 8, dtype=torch.uint8, device="cuda")
+    if dtype == torch.bfloat16:
+        d.maskbits = bits.data_ptr()
     L.call(L.lib.mfc_combine_fwd, d)
     assert relerr(ops.to_nchw(out, Cc).cpu(), ref) < TOL[dtype]
+    if dtype == torch.bfloat16:      # the 1-bit image of the output's sign, for the backward pass
+        assert torch.equal(bits, pack_sign_bits(out))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("dtype", DT)
 def test_bn_backward(M, dtype, mode):
     """BN(+ReLU / +residual ReLU) backward: reduce -> finalize -> apply vs autograd (train-mode BN, 2 groups)."""
@@ -278,7 +290,7 @@ def test_bn_backward(M, dtype, mode):
     beta = (torch.randn(Cc) * 0.2).requires_grad_(True)
     zs = [F.batch_norm(y[g * ipg:(g + 1) * ipg], None, None, gamma, beta, True, 0.1, 1e-5) for g in range(G)]
     z = torch.cat(zs)
-    a = z if mode == 0 else (F.relu(z + res) if mode == 1 else F.relu(z))
+    a = z if mode == 0 else (F.relu(z + res) if mode in (1, 3) else F.relu(z))
     ga = rnd(dtype, N, Cc, H, W, seed=22)
     a.backward(ga)
     coef = torch.zeros(G, 4, Cc)
@@ -298,6 +310,11 @@ def test_bn_backward(M, dtype, mode):
     d.g, d.y, d.dy = ops.view(tg), ops.view(ty, coefd), ops.view(dy)
     if mode == 1:
         d.mask = ops.view(ta)
+    if mode == 3:            # the 1-bit image of the same mask (bf16 only)
+        if dtype != torch.bfloat16:
+            pytest.skip("1-bit masks are a bf16 feature")
+        bits = pack_sign_bits(ta)
+        d.mask = L.View(bits.data_ptr(), 0, ta.shape[1], ta.shape[2], ta.shape[3], 0)
     d.bstats, d.bcoef = bst.data_ptr(), bco.data_ptr()
     d.mask_mode, d.dtype, d.N, d.C, d.images_per_group, d.accumulate = mode, ops.dt_of(ty), N, Cc, ipg, 0
     tol = TOL[dtype] * 2
@@ -360,6 +377,18 @@ def test_mask_add_adjoint_bilinear(M, dtype, hw):
         d.dst, d.scratch = ops.view(dst2), scratch.data_ptr()
         L.call(L.lib.mfc_mask_add, d)
         assert relerr(ops.to_nchw(dst2, Cc).cpu() - 1.0, src.grad) < TOL[dtype] * 2
+    if dtype == torch.bfloat16:     # the mask as a 1-bit image (mask_mode 3), every kernel form
+        bits = pack_sign_bits(tout)
+        for use_scratch in ((False, True) if (hs, ws) != (H, W) else (False,)):
+            dst3 = torch.ones(N, hs, ws, Cc, dtype=dtype, device="cuda")
+            d3 = L.MaskAddDesc()
+            d3.g, d3.dst = ops.view(tg), ops.view(dst3)
+            d3.mask = L.View(bits.data_ptr(), 0, H, W, tout.shape[3], 0)
+            d3.mask_mode, d3.dtype, d3.N, d3.C, d3.accumulate = 3, ops.dt_of(tg), N, Cc, 1
+            if use_scratch:
+                d3.scratch = scratch.data_ptr()
+            L.call(L.lib.mfc_mask_add, d3)
+            assert relerr(ops.to_nchw(dst3, Cc).cpu() - 1.0, src.grad) < TOL[dtype] * 2
 
 
 @pytest.mark.parametrize("dtype", DT)
