@@ -260,7 +260,7 @@ int mfc_bnbwd_finalize(const mfc_bnbwdfin_desc* d, void* stream);
  * up-sampled terms of a combine (residual adds hrnet.py:71,112; fuse sums :250-259).      */
 typedef struct {
     mfc_view g;              /* high-resolution gradient */
-    mfc_view mask;           /* same resolution as g (mode 1) */
+    mfc_view mask;           /* same resolution as g: the tensor whose sign is the mask (mode 1) or its 1-bit image (mode 3, bf16; ptr = bits) */
     mfc_view dst;            /* resolution of the term's source */
     int32_t mask_mode, dtype, N, C, accumulate;
     int32_t pad_;
