@@ -5,17 +5,20 @@ on synthetic 480x640 T=3 clips, BASELINE.json's metric.
 
     python bench.py                                   # 1 GPU, width 32 (the metric's "HRNet-w32"), bf16, B=8
     python bench.py --width 48                        # the reference's hard-coded HRNet-W48
+    python bench.py --gpus N                          # starts N ranks itself (one per GPU, RCCL), relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W     # one rank per GPU, RCCL all-reduce of the flat gradient arena
+           bench.py --gpus N --steps K --warmup W     # the same under an external launcher
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every launch of the
-dominant kernel (the MFMA implicit-GEMM convolution) inside the timed steps; `cpu_baseline` times the CPU
+Prints ONE JSON line (rank 0).  `roofline` describes the kernel with the largest total time in a one-stream profiled
+step that runs AFTER the timed region (HIP events around every launch, on the launch stream; rows named as rocprofv3
+names them); `roofline_conv` is the same for the dominant implicit-GEMM convolution; `cpu_baseline` times the CPU
 oracle (the restatement of the reference step, oracle/mfcnet_oracle.py) on this host's cores.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,63 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_HBM_GBPS = 8000.0                              # HBM3E, MI355X_MICROARCH.md
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
-NT_SLOTS = [1, 2, 3, 4, 6]
 
 
-def synth(B, T, H, W, nc, seed, device, depth=False, optflow=False):
-    """SURVEY.md 8(d): N(0,1) frames, U[0,1) depth maps, 3*N(0,1) pixel-unit flows (constants), uniform class masks."""
-    g = torch.Generator().manual_seed(seed)
-    frames = [torch.randn(B, 3, H, W, generator=g).to(device) for _ in range(T)]
-    mask = torch.randint(0, nc, (B, H, W), generator=g).to(device)
-    dm = [torch.rand(B, 1, H, W, generator=g).to(device) for _ in range(T)] if depth else None
-    fl = [(3.0 * torch.randn(B, 2, H, W, generator=g)).to(device) for _ in range(T - 1)] if optflow else None
-    return frames, mask, dm, fl
-
-
-def pmc_traffic(NT, MT, PM, NW, args):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_round.sh: two separate
-    rocprofv3 --pmc runs of this command, FETCH_SIZE doubled per MI355X_MICROARCH.md; condensed by
-    tools/summarize_profile.py).  bench.py cannot collect counters itself; null when no profile matches the configuration."""
-    import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_w{args.width}_pmc_traffic.json")))      # newest round's passes
-    if args.dtype != "bf16" or (args.batch, args.frames, args.height, args.width_px) != (8, 3, 480, 640) or not found \
-            or args.depth or args.optflow or args.basic or args.single or args.fwd_only:
-        return None, None
-    path = found[-1]
-    tag = os.path.basename(path)
-    with open(path) as f:
-        ks = json.load(f)["kernels"]
-    for name, v in ks.items():
-        if "conv_igemm_kernel" in name and f"Li{NT}ELi{MT}ELi{PM}ELi{NW}E" in name and "DF16b" in name:
-            return v["hbm_bytes_per_launch"], f"profiles/{tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial`)"
-    return None, None
-
-
-def cpu_baseline(width, T, H, W, steps=2):
-    """The CPU oracle's training step on the host cores (bounded sample)."""
-    from oracle import mfcnet_oracle as O
-    torch.manual_seed(0)
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))     # B=1 convolutions stop scaling (and oversubscribe) beyond ~32 threads
-    sd = O.hashed_state(O.mfcnet_table("HRNetMulti-Large", width, 5, T, False, False))
-    net = O.Net(sd, "HRNetMulti-Large", width, 5, T).train()
-    opt = O.make_adam(net, 1e-4)
-    g = torch.Generator().manual_seed(42)
-    frames = [torch.randn(1, 3, H, W, generator=g) for _ in range(T)]
-    mask = torch.randint(0, 5, (1, H, W), generator=g)
-    O.train_step(net, opt, frames, mask)            # warm-up (allocator, thread pool)
-    t0 = time.time()
-    for _ in range(steps):
-        O.train_step(net, opt, frames, mask)
-    dt = time.time() - t0
-    return {"value": round(steps * T / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} full training steps of the CPU oracle, HRNet-w{width} MFCNet, B=1, T={T}, {H}x{W}, fp32"}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -96,17 +47,171 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="eval-mode forward only (no loss / backward / optimizer)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no `roofline` object)")
     ap.add_argument("--serial", action="store_true", help="one stream: no branch lanes / detached weight-gradient streams (for kernel profiles)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+# ----------------------------------------------------------------------------------------------- N ranks from one command
+def launch_ranks(args):
+    """`bench.py --gpus N` without an external launcher: this parent never touches the GPU (no HIP call, torch is not even
+    imported); it starts N fresh ranks under torch.distributed.run on 127.0.0.1, relays rank 0's JSON line and fails unless
+    that line reports n_gpus == N (the replacement of the reference's single-process nn.DataParallel,
+    scripts/train_multiframe_detection.py:107-110)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in r.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or len(lines) != 1:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank run failed (rc {r.returncode}, {len(lines)} result lines)")
+    d = json.loads(lines[0])
+    if d.get("n_gpus") != args.gpus:
+        raise SystemExit(f"bench.py: asked for {args.gpus} GPUs, the ranks report {d.get('n_gpus')}")
+    print(lines[0], flush=True)
+
+
+def synth(B, T, H, W, nc, seed, device, depth=False, optflow=False):
+    """SURVEY.md 8(d): N(0,1) frames, U[0,1) depth maps, 3*N(0,1) pixel-unit flows (constants), uniform class masks."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    frames = [torch.randn(B, 3, H, W, generator=g).to(device) for _ in range(T)]
+    mask = torch.randint(0, nc, (B, H, W), generator=g).to(device)
+    dm = [torch.rand(B, 1, H, W, generator=g).to(device) for _ in range(T)] if depth else None
+    fl = [(3.0 * torch.randn(B, 2, H, W, generator=g)).to(device) for _ in range(T - 1)] if optflow else None
+    return frames, mask, dm, fl
+
+
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/profile_round.sh: separate rocprofv3 --pmc runs of
+    this command, FETCH_SIZE doubled per MI355X_MICROARCH.md; condensed by tools/summarize_profile.py).  bench.py cannot
+    collect counters itself; null when no committed profile matches the configuration."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_w{args.width}_pmc_traffic.json")))      # newest round's passes
+    if args.dtype != "bf16" or (args.batch, args.frames, args.height, args.width_px) != (8, 3, 480, 640) or not found \
+            or args.depth or args.optflow or args.basic or args.single or args.fwd_only:
+        return None, None
+    path = found[-1]
+    with open(path) as f:
+        ks = json.load(f)["kernels"]
+    v = ks.get(kernel)
+    if v is None:
+        return None, None
+    return v["hbm_bytes_per_launch"], f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial`)"
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline (rank 0, N = 1)
+def host_cpu():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
+def cpu_baseline(width, T, H, W):
+    """The CPU oracle on the host cores, bounded samples: the MFCNet training step (the value), its
+    eval-mode forward, and the single-frame HRNet B=2 training step that stands in for BASELINE configs[0]."""
+    import torch
+    from oracle import mfcnet_oracle as O
+    torch.manual_seed(0)
+    model, logical, usable = host_cpu()
+    threads = min(usable, 64)                     # B=1 convolutions stop scaling (and oversubscribe) beyond the physical cores
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(42)
+
+    def timed(fn, n):
+        fn()                                      # warm-up (allocator, thread pool)
+        t0 = time.time()
+        for _ in range(n):
+            fn()
+        return (time.time() - t0) / n
+
+    sd = O.hashed_state(O.mfcnet_table("HRNetMulti-Large", width, 5, T, False, False))
+    net = O.Net(sd, "HRNetMulti-Large", width, 5, T).train()
+    opt = O.make_adam(net, 1e-4)
+    frames = [torch.randn(1, 3, H, W, generator=g) for _ in range(T)]
+    mask = torch.randint(0, 5, (1, H, W), generator=g)
+    t_step = timed(lambda: O.train_step(net, opt, frames, mask), 3)
+    net.eval()
+    with torch.no_grad():
+        t_fwd = timed(lambda: net(frames), 3)
+    del net, opt
+    # BASELINE configs[0]: single-frame model, batch 2, full step (`F.log_softmax(model(x))`, scripts/train_toolpose_segmentation.py:162-163);
+    # its "UNet" model type does not exist in the reference (BASELINE.md section 3) -- the single-frame HRNet-W48 stands in
+    sds = O.hashed_state(O.hrnet_table(48, 5, ""))
+    sn = O.SingleNet(sds, 48, 5).train()
+    so = torch.optim.Adam(sn.params(""), lr=1e-4)
+    xs = torch.randn(2, 3, H, W, generator=g)
+    ms = torch.randint(0, 5, (2, H, W), generator=g)
+
+    def single_step():
+        so.zero_grad(set_to_none=True)
+        loss, _ = O.total_loss(sn(xs), ms, 5)
+        loss.backward()
+        so.step()
+    t_single = timed(single_step, 2)
+    return {"value": round(T / t_step, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "host": {"cpu_model": model, "logical_cpus": logical, "usable_cpus": usable, "torch_threads": threads},
+            "sample": f"3 full training steps of the CPU oracle (fwd + loss + bwd + Adam), HRNet-w{width} MFCNet, B=1, T={T}, {H}x{W}, fp32",
+            "fwd_only": {"value": round(T / t_fwd, 4), "unit": "frames/s", "sample": f"3 eval-mode forwards of the same clip (B=1, T={T})"},
+            "single_frame_b2_step": {"value": round(2 / t_single, 4), "unit": "frames/s",
+                                     "sample": f"2 full training steps of the single-frame HRNet-w48 (model_type 'HRNet'), B=2, {H}x{W}, fp32 "
+                                               "(stand-in for BASELINE.json configs[0])"}}
+
+
+def roofline_of(row, steps, dtype, traffic=(None, None)):
+    """`roofline` object of one profiler row: which roof binds it (its algorithmic bytes at the HBM peak vs its flops at the
+    dense MFMA peak -- whichever takes longer) and the fraction of that roof it reaches."""
+    n = row["launches"]
+    avg_ms = row["ms"] / n
+    tfl = row["flops"] / n / (avg_ms * 1e-3) / 1e12
+    gbps = row["bytes"] / n / (avg_ms * 1e-3) / 1e9
+    peak = PEAK_TFLOPS[dtype]
+    hbm_bound = row["bytes"] / (PEAK_HBM_GBPS * 1e9) >= row["flops"] / (peak * 1e12)
+    return {"bound": "hbm" if hbm_bound else "mfma", "kernel": row["name"],
+            "achieved": round(gbps if hbm_bound else tfl, 2), "peak": PEAK_HBM_GBPS if hbm_bound else peak,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(gbps / PEAK_HBM_GBPS if hbm_bound else tfl / peak, 4),
+            "mfma_tflops": round(tfl, 2), "mfma_frac": round(tfl / peak, 4), "hbm_gbps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4),
+            "traffic": traffic[0], "traffic_source": traffic[1], "algorithmic_bytes_per_launch": round(row["bytes"] / n),
+            "flops_per_launch": row["flops"] / n, "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": n // max(steps, 1),
+            "ms_per_step": round(row["ms"] / max(steps, 1), 3)}
+
+
+def main():
+    args = parse_args()
+    external = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not external:
+        return launch_ranks(args)                 # (before anything touches the GPU)
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); they must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    local = local % torch.cuda.device_count()          # (gloo rehearsal: several ranks may share one GPU)
+    ndev = torch.cuda.device_count()
+    if local >= ndev and args.backend == "nccl":
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own (LOCAL_RANK {local}, {ndev} visible); one rank per GPU")
+    local = local % ndev                               # (gloo rehearsal: several ranks may share one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
@@ -125,6 +230,12 @@ def main():
             dist.init_process_group("nccl", device_id=device, pg_options=opts)
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group of {dist.get_world_size()} ranks for --gpus {args.gpus}")
+        devs = [None] * world
+        dist.all_gather_object(devs, (socket.gethostname(), local))
+        if args.backend == "nccl" and len(set(devs)) != world:
+            raise SystemExit(f"bench.py: ranks share a device: {devs}")
 
     if os.environ.get("MFC_DUMMY_STREAMS"):         # experiment: streams created (and used) by others before ours shift the HW-queue mapping
         _dummies = [torch.cuda.Stream() for _ in range(int(os.environ["MFC_DUMMY_STREAMS"]))]
@@ -148,10 +259,9 @@ def main():
                     optflow_inputs=args.optflow, depth_inputs=args.depth)
     model = model.to(device)
     model = model.eval() if args.fwd_only else model.train()
-    if os.environ.get("MFC_MASK_BITS"):            # tuning: 0 = the BatchNorm backward reads the ReLU mask from the bf16 tensor
-        model.relu_mask_bits = os.environ["MFC_MASK_BITS"] != "0"
-    if os.environ.get("MFC_BATCH_WGRAD"):          # tuning: 0 = one launch per weight gradient
-        model.batch_wgrad = os.environ["MFC_BATCH_WGRAD"] != "0"
+    for env, attr in (("MFC_MASK_BITS", "relu_mask_bits"), ("MFC_BATCH_WGRAD", "batch_wgrad")):      # tuning switches of the plan
+        if os.environ.get(env):
+            setattr(model, attr, os.environ[env] != "0")
     opt = mfc.FlatAdam(model, lr=1e-4)
     frames, mask, depth, flow = synth(B, T, H, W, nc, 42 + 2000 + rank, device, args.depth, args.optflow)
 
@@ -179,64 +289,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # tuning switches of the library (defaults are the measured optima; include/mfcnet_hip.h lists them).  Set before the plan is built.
+    for env, flag in (("MFC_WGRAD_BLOCKS", 11), ("MFC_BNRED_BLOCKS", 27), ("MFC_CONV_GEMM", 23), ("MFC_PROBE_STREAMS", 22),
+                      ("MFC_WGRAD_MAXPX", 21), ("MFC_CONV_NW8", 19), ("MFC_CONV_FILL_PCT", 18), ("MFC_CONV_GRID", 4),
+                      ("MFC_ASYNC_PRIO", 16), ("MFC_SKIP_KINDS", 15), ("MFC_ASYNC_ON_LANE", 13), ("MFC_OWN_MAIN", 14),
+                      ("MFC_LANE_STREAMS", 12), ("MFC_LANES", 9), ("MFC_ASYNC_STREAMS", 10)):
+        if os.environ.get(env):
+            L.lib.mfc_set_flag(flag, int(os.environ[env]))
     if args.serial:
         L.lib.mfc_set_flag(9, 0)
-    if os.environ.get("MFC_WGRAD_BLOCKS"):          # (must be set before the plan is built: it sizes the partial-sum slices)
-        L.lib.mfc_set_flag(11, int(os.environ["MFC_WGRAD_BLOCKS"]))
-    if os.environ.get("MFC_BNRED_BLOCKS"):
-        L.lib.mfc_set_flag(27, int(os.environ["MFC_BNRED_BLOCKS"]))
-    if os.environ.get("MFC_CONV_GEMM"):
-        L.lib.mfc_set_flag(23, int(os.environ["MFC_CONV_GEMM"]))
-    if os.environ.get("MFC_PROBE_STREAMS"):
-        L.lib.mfc_set_flag(22, int(os.environ["MFC_PROBE_STREAMS"]))
-    if os.environ.get("MFC_WGRAD_MAXPX"):           # (before the plan is built, like MFC_WGRAD_BLOCKS)
-        L.lib.mfc_set_flag(21, int(os.environ["MFC_WGRAD_MAXPX"]))
-    if os.environ.get("MFC_CONV_NW8"):              # weight (%) of the 8-wave conv geometries in the search (0 = never); before the plan is built
-        L.lib.mfc_set_flag(19, int(os.environ["MFC_CONV_NW8"]))
-    if os.environ.get("MFC_CONV_FILL_PCT"):         # before the plan is built (the packed weight layouts depend on the geometry)
-        L.lib.mfc_set_flag(18, int(os.environ["MFC_CONV_FILL_PCT"]))
-    if os.environ.get("MFC_CONV_GRID"):             # before the plan is built (sizes nothing, but the layouts are queried then)
-        L.lib.mfc_set_flag(4, int(os.environ["MFC_CONV_GRID"]))
-    if os.environ.get("MFC_ASYNC_PRIO"):            # before the first program run (read when the streams are created)
-        L.lib.mfc_set_flag(16, int(os.environ["MFC_ASYNC_PRIO"]))
-    if os.environ.get("MFC_SKIP_KINDS"):            # what-if timing only (results are wrong)
-        L.lib.mfc_set_flag(15, int(os.environ["MFC_SKIP_KINDS"]))
-    if os.environ.get("MFC_ASYNC_ON_LANE"):
-        L.lib.mfc_set_flag(13, int(os.environ["MFC_ASYNC_ON_LANE"]))
-    if os.environ.get("MFC_OWN_MAIN"):
-        L.lib.mfc_set_flag(14, int(os.environ["MFC_OWN_MAIN"]))
-    if os.environ.get("MFC_LANE_STREAMS"):
-        L.lib.mfc_set_flag(12, int(os.environ["MFC_LANE_STREAMS"]))
-    if os.environ.get("MFC_LANES"):
-        L.lib.mfc_set_flag(9, int(os.environ["MFC_LANES"]))
-    if os.environ.get("MFC_ASYNC_STREAMS"):
-        L.lib.mfc_set_flag(10, int(os.environ["MFC_ASYNC_STREAMS"]))
     for _ in range(args.warmup):
         step()
     sync()
-    # HIP events bracket every conv / wgrad launch of the LAST timed step only: recording events around ~1100 launches
-    # per step costs ~7 % of a step (it breaks back-to-back dispatch), so one profiled step keeps `value` honest while the
-    # roofline is still measured live inside the timed region, on the launch stream.
-    prof_steps = 0 if args.no_prof else 1
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - prof_steps:
-            # the profiled step runs every record on ONE stream: with the branch lanes / detached wgrad streams a launch shares
-            # the GPU with other kernels and its event-bracketed time would no longer be the kernel's own duration
-            L.lib.mfc_set_flag(9, 0)
-            L.lib.mfc_prof_enable(1)
         loss = step()
     sync()
     dt = time.perf_counter() - t0
-    L.lib.mfc_prof_enable(0)
-    L.lib.mfc_set_flag(9, 0 if args.serial else 3)
-    prof = L.ProfResult()
-    L.lib.mfc_prof_collect(C.byref(prof))
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     final_loss = float(loss.detach())
+
+    # The profiled step runs AFTER the timed region (it is not part of `value`): every record on ONE stream -- with the branch
+    # lanes / the detached weight-gradient stream a launch shares the GPU with other kernels and its event-bracketed time would
+    # not be the kernel's own duration -- and HIP events on that stream around every launch (mfc_prof_*).
+    rows, prof_steps = [], 0
+    if not args.no_prof:                           # (every rank runs the two extra steps: they contain collectives when N > 1)
+        prof_steps = 1
+        L.lib.mfc_set_flag(9, 0)
+        step()                                     # one un-profiled serial step first (stream switch)
+        torch.cuda.synchronize()
+        L.lib.mfc_prof_enable(1)
+        step()
+        torch.cuda.synchronize()
+        L.lib.mfc_prof_enable(0)
+        L.lib.mfc_set_flag(9, 0 if args.serial else 3)
+        rows = L.prof_collect()
 
     extra = ("+depth" if args.depth else "") + ("+optflow" if args.optflow else "")
     cfg_label = ("per-GPU share of BASELINE.json configs[3]" if (T, H, W, B, extra) == (3, 480, 640, 4, "+depth+optflow") else
@@ -245,56 +335,37 @@ def main():
                  "BASELINE.json configs[2]" if (T, H, W, B) == (3, 480, 640, 8) else
                  "per-GPU share of BASELINE.json configs[4]" if (T, H, W, B, args.width) == (5, 720, 960, 8, 48) else "custom size")
     if rank == 0:
-        # dominant kernel = the conv_igemm instantiation (one profiler bucket per <NT, MT, PMAX>, as rocprof names them) with the
-        # largest total time in the profiled step; bucket layout: include/mfcnet_hip.h (mfc_prof_result)
-        dt_base = 64 if args.dtype == "bf16" else 0
-        roof = None
-        conv = [(dt_base + s, s) for s in range(41)]          # 40 = conv_gemm1x1_kernel (big 1x1 convolutions)
-        live = [(b, s) for b, s in conv if prof.launches[b]]
-        if live:
-            best, bslot = max(live, key=lambda bs: prof.ms[bs[0]])
-            n = prof.launches[best]
-            avg_ms = prof.ms[best] / n
-            achieved = prof.flops[best] / n / (avg_ms * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[args.dtype]
-            if bslot == 40:
-                NT, MT, PM, NW = 4, 8, 0, 8
-                kname = "conv_gemm1x1_kernel"
-            else:
-                NW = 8 if bslot >= 20 else 4
-                NT = NT_SLOTS[(bslot % 20) // 4]
-                MT, PM = [(4, 3), (4, 6), (2, 4), (2, 10)][bslot % 4]
-                kname = f"conv_igemm_kernel<{'__bf16' if args.dtype == 'bf16' else 'float'}, {NT}, {MT}, {PM}, {NW}>"
-            fam_ms = sum(prof.ms[b] for b, _ in conv)
-            fam_fl = sum(prof.flops[b] for b, _ in conv)
-            wgb = [128 + dt_base + s for s in range(64)]
-            wg_ms = sum(prof.ms[b] for b in wgb)
-            wg_fl = sum(prof.flops[b] for b in wgb)
-            traffic, tsrc = pmc_traffic(NT, MT, PM, NW, args)
-            # which roof binds this kernel: its algorithmic bytes at the HBM peak vs its flops at the dense MFMA peak
-            abytes = prof.bytes[best] / n
-            gbps = abytes / (avg_ms * 1e-3) / 1e9
-            hbm_bound = abytes / (PEAK_HBM_GBPS * 1e9) > (prof.flops[best] / n) / (peak * 1e12)
-            roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
-                    "achieved": round(gbps if hbm_bound else achieved, 2), "peak": PEAK_HBM_GBPS if hbm_bound else peak,
-                    "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(gbps / PEAK_HBM_GBPS if hbm_bound else achieved / peak, 4),
-                    "mfma_tflops": round(achieved, 2), "mfma_frac": round(achieved / peak, 4),
-                    "hbm_gbps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4),
-                    "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": round(prof.bytes[best] / n),
-                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": n // max(prof_steps, 1),
-                    "flops_per_launch": prof.flops[best] / n,
-                    "all_conv_igemm_tflops": round(fam_fl / (fam_ms * 1e-3) / 1e12, 2) if fam_ms else None,
-                    "all_wgrad_tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 2) if wg_ms else None,
-                    "conv_ms_per_step": round(fam_ms / max(prof_steps, 1), 3), "wgrad_ms_per_step": round(wg_ms / max(prof_steps, 1), 3),
-                    "profiled_steps": prof_steps, "profiled_step_streams": "serial"}
+        roof = roof_conv = None
+        timed_rows = [r for r in rows if r["bytes"] > 0 or r["flops"] > 0]
+        if timed_rows:
+            top = timed_rows[0]                                                   # rows come sorted by total time
+            roof = roofline_of(top, prof_steps, args.dtype, pmc_traffic(top["name"], args))
+            tot_ms = sum(r["ms"] for r in rows)
+            fam = lambda pre: [r for r in rows if r["name"].startswith(pre)]
+            def fam_sum(pre):
+                rs = fam(pre)
+                ms, fl, by = sum(r["ms"] for r in rs), sum(r["flops"] for r in rs), sum(r["bytes"] for r in rs)
+                return {"ms_per_step": round(ms / prof_steps, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms and fl else None,
+                        "gbps": round(by / (ms * 1e-3) / 1e9, 1) if ms and by else None}
+            roof.update({"share_of_profiled_step": round(top["ms"] / tot_ms, 4), "profiled_step_ms": round(tot_ms / prof_steps, 3),
+                         "profiled_steps": prof_steps, "profiled_step_streams": "serial, after the timed region",
+                         "families": {k: fam_sum(k) for k in ("conv_igemm_kernel", "conv_gemm1x1_kernel", "conv_wgrad", "wgrad_gemm1x1_kernel",
+                                                                "bnbwd_", "combine_", "mask_add", "bn_finalize")},
+                         "top5": [{"kernel": r["name"], "ms_per_step": round(r["ms"] / prof_steps, 3), "launches": r["launches"] // prof_steps}
+                                  for r in rows[:5]]})
+            convs = [r for r in timed_rows if r["name"].startswith("conv_igemm_kernel")]
+            if convs:
+                roof_conv = roofline_of(convs[0], prof_steps, args.dtype, pmc_traffic(convs[0]["name"], args))
         out = {"metric": f"frames/sec ({H}x{W}, T={T}, HRNet {'single-frame' if args.single else 'MFCNet'}) {'fwd' if args.fwd_only else 'fwd+bwd'}", "value": round(world * B * T * args.steps / dt, 2),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"{'single-frame HRNet' if args.single else 'MFCNet'}{'-Basic' if args.basic else ''} T={T} {'RGB' + extra if extra else 'RGB-only'} (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, {'eval forward only' if args.fwd_only else 'fwd+bwd+Adam'} "
                                       f"({cfg_label})", "width": args.width, "global_batch": world * B,
-                          "frames_per_clip": T, "parallelism": f"dp{world}", "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
-               "roofline": roof}
+                          "frames_per_clip": T, "parallelism": f"dp{world}", "ranks": world,
+                          "backend": (args.backend if world > 1 else None), "launcher": "external" if external else "bench.py",
+                          "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
+               "roofline": roof, "roofline_conv": roof_conv}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width, T, H, W)
         print(json.dumps(out), flush=True)

@@ -187,6 +187,7 @@ int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream);
 /* the same for a DEVICE-resident table of n descriptors in one launch (max_Cp = largest Cp in the table).  The rows must not
  * depend on each other or on work still in flight; the plan uses it for eval-mode BatchNorms (coefficients from the running
  * statistics, hrnet.py:31 in `.eval()`), whose ~300 one-block launches otherwise sit on the forward critical path. */
+/* (every row needs 1 <= G <= 8 like mfc_bn_finalize; the table lives on the device, so the CALLER validates it -- rows that violate it are skipped) */
 int mfc_bn_finalize_batch(const mfc_bnfin_desc* table_dev, int32_t n, int32_t max_Cp, void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -307,6 +308,8 @@ int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, void* strea
  * wrt logits (src/engine.py:65-66, src/loss.py:31-63).  acc: fp32[32]:
  *   [0] sum w_t*(-logp_t)  [1] sum w_t  [2+c] I_c = sum p_c*[t==c]  [10+c] sum p_c  [18+c] sum [t==c]   (c < 8)
  *   [26] nll  [27] soft-jaccard  [28] w_nll*nll + w_jac*jaccard
+ *   [29] number of targets outside [0, nc): such pixels contribute nothing to the NLL term (and count as "no class" in the Jaccard
+ *        sums) instead of indexing out of bounds; nn.NLLLoss raises on them -- callers that want that check acc[29] (mfc_loss(check_labels=True))
  * mfc_loss_fwd = mfc_loss_partial (zeroes acc, accumulates [0..25] over this call's B clips) + mfc_loss_finalize
  * ([26..28] from the sums).  Data-parallel ranks all-reduce (SUM) acc[0..25] between the two calls: the reference
  * evaluates both terms over the whole gathered batch (engine.py:64-66 runs after DataParallel's gather; the Jaccard
@@ -396,18 +399,14 @@ int mfc_graph_destroy(void* exec);
  * synchronises the stream and returns the stream time per record and repetition in ms_out[n] */
 int mfc_program_profile(const mfc_op* ops, int32_t n, int32_t reps, float* ms_out, void* stream);
 /* In-process kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
- * While enabled, every conv forward/dgrad and wgrad launch is bracketed by two events; mfc_prof_collect
- * synchronises and sums elapsed time, launches and algorithmic FLOPs per bucket.
- * bucket = family*128 + dtype*64 + slot (dtype 0 = fp32, 1 = bf16);
- *   family 0 = conv_igemm_kernel<T, NT, MT, PMAX>: slot = ntIndex*4 + variant, NT in {1,2,3,4,6} -> ntIndex 0..4,
- *              variant 0..3 = <MT,PMAX> in {<4,3>, <4,6>, <2,4>, <2,10>}, +20 for the 8-wave instantiations (NW = 8)
- *              (one bucket per kernel instantiation, as rocprof sees it); slot 40 = conv_gemm1x1_kernel (big 1x1 convolutions, bf16)
- *   family 1 = weight gradient: slot 0..2 generic kernel (TPW 8/16/28), 8..10 fast kernel (TB 1/3/11), 16..17 wave kernel (TB 3/11),
- *              24 = wgrad_gemm1x1_kernel */
-#define MFC_PROF_BUCKETS 256
-typedef struct { double ms[MFC_PROF_BUCKETS]; double flops[MFC_PROF_BUCKETS]; double bytes[MFC_PROF_BUCKETS]; int64_t launches[MFC_PROF_BUCKETS]; } mfc_prof_result;
+ * While enabled, every kernel launch of the entry points above is bracketed by two events recorded on ITS stream;
+ * mfc_prof_collect synchronises them and sums elapsed time, launches, algorithmic FLOPs and algorithmic bytes (the tensors a launch
+ * must touch once) per kernel.  Rows are keyed by the kernel's NAME as rocprofv3 prints it (demangled, e.g.
+ * "conv_wgrad_wave_kernel<3, 3, 2, 2, 4, 1>", "bnbwd_reduce_kernel<__bf16>"), so the rows are those of the rocprofv3 kernel-stats tables
+ * under profiles/.  Only meaningful when every record runs on one stream (mfc_set_flag(9, 0)): with lanes a launch shares the GPU. */
+typedef struct { char name[120]; double ms, flops, bytes; int64_t launches; } mfc_prof_entry;
 int mfc_prof_enable(int on);
-int mfc_prof_collect(mfc_prof_result* out);     /* synchronises the recorded events, fills `out`, clears the log */
+int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the recorded events, fills out[0..n), clears the log; returns n (< 0: error) */
 
 /* Tuning switches (defaults are the measured optima; the tools/ scripts sweep them).  Process-global, not thread-safe.
  *   1  wgrad: use ds_read_b64_tr_b16 (1)            2  conv: force pixel-tile MT (0 = search)     3  wgrad: K-split mode (0)

@@ -93,8 +93,17 @@ __device__ inline void bilin_src(int dst, int in_size, int out_size, int& i0, in
 
 // event-based kernel timing (runtime.hip)
 extern int g_mfc_prof_on;
-void mfc_prof_before(hipStream_t st, int bucket, double flops, double bytes);
+// `name` must be a string with static storage: the kernel name as rocprofv3 prints it (demangled form); one profile row per name
+void mfc_prof_before(hipStream_t st, const char* name, double flops, double bytes);
 void mfc_prof_after(hipStream_t st);
+#include <cstdio>
+// name of a template instantiation, built once (function-static buffer)
+#define MFC_PROF_NAME(buf, ...) static char buf[120]; if (!buf[0]) snprintf(buf, sizeof(buf), __VA_ARGS__)
+// bracket an element-wise launch: MFC_PROF_EW(st, "kernel<%s>", tname, bytes) ... launch ... MFC_PROF_END(st)
+#define MFC_PROF_END(st) do { if (g_mfc_prof_on) mfc_prof_after(st); } while (0)
+template <typename T> inline const char* mfc_tname();
+template <> inline const char* mfc_tname<float>() { return "float"; }
+template <> inline const char* mfc_tname<bf16_t>() { return "__bf16"; }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #define MFC_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return MFC_ERR_LAUNCH; } while (0)

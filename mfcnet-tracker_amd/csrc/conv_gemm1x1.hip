@@ -352,7 +352,7 @@ int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st) {
     if (g_mfc_prof_on) {
         const double flops = 2.0 * k.M * (double)d->Cout * (double)d->Cin;
         const double bytes = (double)k.M * (k.Cin_p + k.Cout_p) * 2.0;
-        mfc_prof_before(st, 0 * 128 + 64 + 40, flops, bytes);       // conv family, bf16, slot 40 (conv_gemm1x1_kernel)
+        mfc_prof_before(st, "conv_gemm1x1_kernel", flops, bytes);
     }
     hipLaunchKernelGGL(conv_gemm1x1_kernel, dim3(grid), dim3(512), G_LDS, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);

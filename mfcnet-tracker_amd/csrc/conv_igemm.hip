@@ -700,12 +700,11 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
         attr_set = true;
     }
     if (g_mfc_prof_on) {
-        const int nti = NT == 1 ? 0 : NT == 2 ? 1 : NT == 3 ? 2 : NT == 4 ? 3 : 4;
-        const int slot = nti * 4 + (MT == 4 ? (PMAX == 3 ? 0 : 1) : (PMAX == 4 ? 2 : 3)) + (NW == 8 ? 20 : 0);
+        MFC_PROF_NAME(pname, "conv_igemm_kernel<%s, %d, %d, %d, %d>", mfc_tname<T>(), NT, MT, PMAX, NW);
         const double E = sizeof(T) == 2 ? 8.0 : 4.0;
         const double flops = 2.0 * k.N * k.Hl * k.Wl * (double)k.Cout * k.TA * k.TB * (k.Cin_g * E);
         const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_g * 16.0) / (k.osh * k.osw) + (double)k.N * k.Hl * k.Wl * k.Cout_p * sizeof(T);
-        mfc_prof_before(st, 0 * 128 + (sizeof(T) == 2 ? 64 : 0) + slot, flops, bytes);
+        mfc_prof_before(st, pname, flops, bytes);
     }
     hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT, PMAX, NW>), dim3(grid), dim3(NW * 64), lds, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);

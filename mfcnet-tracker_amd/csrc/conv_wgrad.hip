@@ -842,10 +842,10 @@ static int wgrad_launch(const WgradK& k, size_t lds, int Y, hipStream_t st) {
         attr_set = true;
     }
     if (g_mfc_prof_on) {
-        const int slot = TPW == 8 ? 0 : TPW == 16 ? 1 : 2;
+        MFC_PROF_NAME(pname, "conv_wgrad_kernel<%s, %d, %s>", mfc_tname<T>(), TPW, TR ? "true" : "false");
         const double flops = 2.0 * k.N * k.Hout * k.Wout * (double)k.Co16 * k.Ci16 * k.TA * k.TB;
         const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_p + (double)k.N * k.Hout * k.Wout * k.Cout_p) * sizeof(T);
-        mfc_prof_before(st, 1 * 128 + (sizeof(T) == 2 ? 64 : 0) + slot, flops, bytes);
+        mfc_prof_before(st, pname, flops, bytes);
     }
     hipLaunchKernelGGL((conv_wgrad_kernel<T, TPW, TR>), dim3(k.splits, Y), dim3(256), lds, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);
@@ -863,7 +863,8 @@ static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st)
     if (g_mfc_prof_on) {
         const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB;
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
-        mfc_prof_before(st, 1 * 128 + 64 + 8 + (TB == 1 ? 0 : TB == 3 ? 1 : 2), flops, bytes);
+        MFC_PROF_NAME(pname, "conv_wgrad_fast_kernel<%d, %d, %d, %s>", TB, WCO, WCI, BIG ? "true" : "false");
+        mfc_prof_before(st, pname, flops, bytes);
     }
     hipLaunchKernelGGL((conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>), dim3(f.splits * Y), dim3(256), lds, st, f);
     if (g_mfc_prof_on) mfc_prof_after(st);
@@ -945,7 +946,8 @@ static int wgrad_wave_launch(const WgradW& f, const WgradBatch& tb, size_t lds, 
     if (g_mfc_prof_on) {
         const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB * tb.n;
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0 * tb.n;
-        mfc_prof_before(st, 1 * 128 + 64 + 16 + (TB == 3 ? 0 : 1), flops, bytes);
+        MFC_PROF_NAME(pname, "conv_wgrad_wave_kernel<%d, %d, %d, %d, %d, %d>", TAA, TB, WCO, WCI, XP, PF);
+        mfc_prof_before(st, pname, flops, bytes);
     }
     hipLaunchKernelGGL((conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP, PF>), dim3(f.splits * Y * tb.n), dim3(256), lds, st, f, tb);
     if (g_mfc_prof_on) mfc_prof_after(st);

@@ -9,6 +9,11 @@
 // Reference operators replaced: see include/mfcnet_hip.h.
 #include "common.h"
 
+// event-profiler bracket of an element-wise launch: the row is named like the kernel rocprofv3 reports; BYTES = the tensors the launch
+// must touch once (its algorithmic HBM traffic)
+#define EW_PROF(st, KERNEL, DTYPE, BYTES) do { if (g_mfc_prof_on) mfc_prof_before(st, (DTYPE) == MFC_BF16 ? KERNEL "<__bf16>" : KERNEL "<float>", 0.0, (double)(BYTES)); } while (0)
+static inline double view_bytes(const mfc_view& v, int N, int C, int esz) { return v.ptr ? (double)N * v.H * v.W * C * esz : 0.0; }
+
 // ------------------------------------------------------------------ BN finalize
 // sum of the R replica rows of one (group, stat, channel) cell: 32 independent loads in flight
 __device__ inline double replica_sum(const float* base, size_t stride) {
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(mfc_bnfin_desc d) {
 __global__ __launch_bounds__(256) void bn_finalize_batch_kernel(const mfc_bnfin_desc* tab) {
     __shared__ float sm[8][64], sv[8][64];
     const mfc_bnfin_desc d = tab[blockIdx.y];
-    if ((int)blockIdx.x * 64 >= d.Cp) return;
+    if ((int)blockIdx.x * 64 >= d.Cp || d.G > 8 || d.G <= 0) return;      // (rows with more than 8 groups would overflow sm / sv: the host validates the table, mfc_bn_finalize rejects them)
     bn_finalize_body(d, blockIdx.x, sm, sv);
 }
 
@@ -84,7 +89,9 @@ extern "C" int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream) {
     if (d->training && !d->stats) return MFC_ERR_INVALID_ARG;
     if (d->C <= 0 || d->C > d->Cp || d->G <= 0) return MFC_ERR_INVALID_ARG;
     if (d->G > 8) return MFC_ERR_UNSUPPORTED;
+    if (g_mfc_prof_on) mfc_prof_before((hipStream_t)stream, "bn_finalize_kernel", 0.0, d->training ? (double)MFC_R * d->G * 2 * d->Cp * 4 : 0.0);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->Cp + 63) / 64), dim3(256), 0, (hipStream_t)stream, *d);
+    MFC_PROF_END((hipStream_t)stream);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -228,15 +235,21 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     bool same = true;
     for (int k = 0; k < d->nsrc; ++k) same = same && d->src[k].H == d->out.H && d->src[k].W == d->out.W;
+    double cbytes = view_bytes(d->out, d->N, d->C, E == 8 ? 2 : 4) + (d->maskbits ? (double)total : 0.0);
+    for (int k = 0; k < d->nsrc; ++k) cbytes += view_bytes(d->src[k], d->N, d->C, E == 8 ? 2 : 4);
     if (same) {
         const int b2 = (int)((total + 511) / 512);
+        EW_PROF(st, "combine_same_kernel", d->dtype, cbytes);
         if (d->dtype == MFC_BF16) hipLaunchKernelGGL(combine_same_kernel<bf16_t>, dim3(b2), dim3(256), 0, st, *d, total, Cg);
         else hipLaunchKernelGGL(combine_same_kernel<float>, dim3(b2), dim3(256), 0, st, *d, total, Cg);
+        MFC_PROF_END(st);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
     }
+    EW_PROF(st, "combine_fwd_kernel", d->dtype, cbytes);
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(combine_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
     else hipLaunchKernelGGL(combine_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -366,8 +379,14 @@ extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
     ppb = ((ppb + PPI - 1) / PPI) * PPI;
     const int bx = (int)((ppg + ppb - 1) / ppb);
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int esz = E == 8 ? 2 : 4;
+        const double t = (double)d->N * d->y.H * d->y.W * d->C * esz;         // one tensor
+        EW_PROF(st, "bnbwd_reduce_kernel", d->dtype, t * (2 + (d->mask_mode == 1 ? 1 : 0) + (d->dy.ptr ? (d->accumulate ? 2 : 1) : 0)) + (d->mask_mode == 3 ? t / 16 : 0));
+    }
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_reduce_kernel<bf16_t>, dim3(bx, G), dim3(Cg * PPI), 0, st, *d, Cg, PPI, ppb, ppg);
     else hipLaunchKernelGGL(bnbwd_reduce_kernel<float>, dim3(bx, G), dim3(Cg * PPI), 0, st, *d, Cg, PPI, ppb, ppg);
+    MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -517,8 +536,10 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
         const unsigned nchunks = (unsigned)((tot + 1023) / 1024);
         const int grid = nchunks < 1024u ? (int)nchunks : 1024;
         hipStream_t s2 = (hipStream_t)stream;
+        EW_PROF(s2, "bnbwd_apply_fin_kernel", d->dtype, (double)tot * 16.0 * (3 + (d->mask_mode == 1 ? 1 : 0)) + (d->mask_mode == 3 ? (double)tot : 0.0));
         if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_apply_fin_kernel<bf16_t>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, nchunks);
         else hipLaunchKernelGGL(bnbwd_apply_fin_kernel<float>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, nchunks);
+        MFC_PROF_END(s2);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
     }
@@ -528,8 +549,10 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
     if (total >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;      // kernels index granules with 32 bits
     const int blocks = (int)((total + 1023) / 1024);
     hipStream_t st = (hipStream_t)stream;
+    EW_PROF(st, "bnbwd_apply_kernel", d->dtype, (double)total * 16.0 * (3 + (d->mask_mode == 1 ? 1 : 0)) + (d->mask_mode == 3 ? (double)total : 0.0));
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
     else hipLaunchKernelGGL(bnbwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -770,8 +793,10 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (d->dst.H == d->g.H && d->dst.W == d->g.W) {
         const int b4 = (int)((total + 1023) / 1024);
+        EW_PROF(st, "mask_add_same_kernel", d->dtype, (double)total * 16.0 * (2 + (d->mask_mode == 1 ? 1 : 0) + (d->accumulate ? 1 : 0)) + (d->mask_mode == 3 ? (double)total : 0.0));
         if (d->dtype == MFC_BF16) hipLaunchKernelGGL(mask_add_same_kernel<bf16_t>, dim3(b4), dim3(256), 0, st, *d, total, Cg);
         else hipLaunchKernelGGL(mask_add_same_kernel<float>, dim3(b4), dim3(256), 0, st, *d, total, Cg);
+        MFC_PROF_END(st);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
     }
@@ -780,6 +805,9 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
         const long t1 = (long)d->N * d->g.H * d->dst.W * Cg;
         if (t1 >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;
         const int b1 = (int)((t1 + 255) / 256), b2 = (int)((total + 255) / 256);
+        // (both passes in one row: the pair is one up-sampling adjoint; bytes = the high-resolution gradient (+ mask) read once + the result)
+        const double hi = (double)d->N * d->g.H * d->g.W * Cg * 16.0;
+        EW_PROF(st, "mask_add_wpass+hpass_kernel", d->dtype, hi * (1 + (d->mask_mode == 1 ? 1 : 0)) + (d->mask_mode == 3 ? hi / 16 : 0) + (double)total * 16.0 * (d->accumulate ? 2 : 1));
         if (d->dtype == MFC_BF16) {
             hipLaunchKernelGGL(mask_add_wpass_kernel<bf16_t>, dim3(b1), dim3(256), 0, st, *d, (unsigned)t1, Cg);
             hipLaunchKernelGGL(mask_add_hpass_kernel<bf16_t>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg);
@@ -787,6 +815,7 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
             hipLaunchKernelGGL(mask_add_wpass_kernel<float>, dim3(b1), dim3(256), 0, st, *d, (unsigned)t1, Cg);
             hipLaunchKernelGGL(mask_add_hpass_kernel<float>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg);
         }
+        MFC_PROF_END(st);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
     }
@@ -864,8 +893,10 @@ extern "C" int mfc_bias_grad(const void* dy, float* db, int32_t dtype, int64_t n
     int ppb = (int)((npix + want - 1) / want);
     ppb = ((ppb + PPI - 1) / PPI) * PPI;
     const int blocks = (int)((npix + ppb - 1) / ppb);
+    EW_PROF(st, "bias_grad_kernel", dtype, (double)npix * Cp * (E == 8 ? 2 : 4));
     if (dtype == MFC_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(blocks, nslab), dim3(Cg * PPI), 0, st, (const bf16_t*)dy, db, (long)npix, Cp, C, Cg, PPI, ppb);
     else hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks, nslab), dim3(Cg * PPI), 0, st, (const float*)dy, db, (long)npix, Cp, C, Cg, PPI, ppb);
+    MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -1030,8 +1061,12 @@ extern "C" int mfc_head_gather_fwd(const mfc_headgather_desc* d, void* stream) {
     const long total = (long)d->B * d->H * d->W;
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
+    const int hesz = d->dtype == MFC_BF16 ? 2 : 4;
+    EW_PROF(st, "head_gather_fwd_kernel", d->dtype, (double)total * d->Cp * hesz + (double)d->T * d->B * d->Hs * d->Ws * d->Lp * hesz
+            + (double)total * 4.0 * ((d->flow[0] ? 2 * (d->T - 1) : 0) + (d->depth[0] ? d->T : 0)));
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total);
     else hipLaunchKernelGGL(head_gather_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total);
+    MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -1167,8 +1202,11 @@ extern "C" int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, 
     }
     const long total = (long)d->B * d->Hs * d->Ws;
     const int blocks = (int)((total + 255) / 256);
+    const int hesz = d->dtype == MFC_BF16 ? 2 : 4;
+    EW_PROF(st, "head_gather_bwd_kernel", d->dtype, (double)d->B * d->H * d->W * d->Cp * hesz + (double)d->T * total * d->Lp * hesz);
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, (bf16_t*)dlogits, (const float*)dU, total);
     else hipLaunchKernelGGL(head_gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, (float*)dlogits, (const float*)dU, total);
+    MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

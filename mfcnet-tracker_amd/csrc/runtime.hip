@@ -6,12 +6,15 @@
 #include <math.h>
 
 // acc layout: [0] sum w_t*(-logp_t)  [1] sum w_t  [2+c] I_c  [10+c] P_c = sum p_c  [18+c] T_c = sum [t==c]
-//             [26] nll  [27] soft-jaccard  [28] total
+//             [26] nll  [27] soft-jaccard  [28] total  [29] number of targets outside [0, nc) (they are ignored; nn.NLLLoss raises on them)
 __global__ __launch_bounds__(256) void loss_fwd_kernel(mfc_loss_desc d, long total) {
     __shared__ float red[26];
+    __shared__ unsigned bad_s;
     if (threadIdx.x < 26) red[threadIdx.x] = 0.f;
+    if (threadIdx.x == 0) bad_s = 0u;
     __syncthreads();
     const long HW = (long)d.H * d.W;
+    unsigned bad = 0;
     float a0 = 0.f, a1 = 0.f, I[8], P[8], Tc[8];
     for (int c = 0; c < 8; ++c) { I[c] = 0.f; P[c] = 0.f; Tc[c] = 0.f; }
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -21,9 +24,17 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(mfc_loss_desc d, long tot
         float se = 0.f;
         for (int c = 0; c < d.nc; ++c) se += expf(x[c] - mx);
         const float lse = mx + logf(se);
-        const int t = (int)d.target[idx];
-        const float wt = d.class_w ? d.class_w[t] : 1.f;
-        a0 += wt * (lse - x[t]); a1 += wt;
+        const long tl = (long)d.target[idx];
+        const bool tok = tl >= 0 && tl < (long)d.nc;        // a label outside the class range (255 "ignore", a corrupt mask) must not index class_w / x
+        const int t = tok ? (int)tl : -1;
+        bad += tok ? 0u : 1u;
+        if (tok) {
+            float xt = x[0];
+#pragma unroll
+            for (int c = 1; c < 8; ++c) xt = (c == t) ? x[c] : xt;
+            const float wt = d.class_w ? d.class_w[t] : 1.f;
+            a0 += wt * (lse - xt); a1 += wt;
+        }
         for (int c = 1; c < d.nc; ++c) {
             const float pc = expf(x[c] - lse);
             P[c] += pc;
@@ -39,8 +50,10 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(mfc_loss_desc d, long tot
         atomicAdd(&red[0], a0); atomicAdd(&red[1], a1);
         for (int c = 1; c < d.nc; ++c) { atomicAdd(&red[2 + c], I[c]); atomicAdd(&red[10 + c], P[c]); atomicAdd(&red[18 + c], Tc[c]); }
     }
+    if (bad) atomicAdd(&bad_s, bad);
     __syncthreads();
     if (threadIdx.x < 26 && red[threadIdx.x] != 0.f) atomicAdd(d.acc + threadIdx.x, red[threadIdx.x]);
+    if (threadIdx.x == 0 && bad_s) atomicAdd(d.acc + 29, (float)bad_s);
 }
 
 __global__ void loss_finalize_kernel(mfc_loss_desc d) {
@@ -102,8 +115,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(mfc_loss_desc d, long tot
         float se = 0.f;
         for (int c = 0; c < d.nc; ++c) se += expf(x[c] - mx);
         const float lse = mx + logf(se);
-        const int t = (int)d.target[idx];
-        const float wt = (d.class_w ? d.class_w[t] : 1.f) / Wsum;
+        const long tl = (long)d.target[idx];
+        const bool tok = tl >= 0 && tl < (long)d.nc;
+        const int t = tok ? (int)tl : -1;                    // out-of-range target: no NLL term, "no class" for the Jaccard term (as in the forward)
+        const float wt = tok ? (d.class_w ? d.class_w[t] : 1.f) / Wsum : 0.f;
         float p[8], a[8], dot = 0.f;
         for (int c = 0; c < d.nc; ++c) {
             p[c] = expf(x[c] - lse);
@@ -197,16 +212,21 @@ extern "C" int mfc_adam_step(float* p, const float* g, float* m, float* v, int64
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     const long blocks = ((n + 3) / 4 + 255) / 256;
+    if (g_mfc_prof_on) mfc_prof_before((hipStream_t)stream, "adam_kernel", 0.0, 28.0 * (double)n);
     hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale);
+    MFC_PROF_END((hipStream_t)stream);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
 
 // ------------------------------------------------------------------ event profiler
+// Rows are keyed by kernel NAME (the string rocprofv3 prints for that kernel, demangled), so bench.py's `roofline` object and the
+// committed rocprofv3 kernel-stats table talk about the same rows.
 #include <vector>
+#include <string.h>
 int g_mfc_prof_on = 0;
 namespace {
-struct ProfRec { hipEvent_t a, b; int bucket; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; const char* name; double flops, bytes; };
 std::vector<ProfRec> g_log;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
@@ -214,27 +234,32 @@ hipEvent_t get_event() {
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 }
-void mfc_prof_before(hipStream_t st, int bucket, double flops, double bytes) {
-    ProfRec r; r.a = get_event(); r.b = get_event(); r.bucket = bucket; r.flops = flops; r.bytes = bytes;
+void mfc_prof_before(hipStream_t st, const char* name, double flops, double bytes) {
+    ProfRec r; r.a = get_event(); r.b = get_event(); r.name = name; r.flops = flops; r.bytes = bytes;
     (void)hipEventRecord(r.a, st);
     g_log.push_back(r);
 }
 void mfc_prof_after(hipStream_t st) { (void)hipEventRecord(g_log.back().b, st); }
 extern "C" int mfc_prof_enable(int on) { g_mfc_prof_on = on; return MFC_OK; }
-extern "C" int mfc_prof_collect(mfc_prof_result* out) {
-    if (!out) return MFC_ERR_INVALID_ARG;
-    for (int i = 0; i < MFC_PROF_BUCKETS; ++i) { out->ms[i] = 0; out->flops[i] = 0; out->bytes[i] = 0; out->launches[i] = 0; }
+extern "C" int mfc_prof_collect(mfc_prof_entry* out, int32_t cap) {
+    if (!out || cap <= 0) return MFC_ERR_INVALID_ARG;
+    int n = 0;
     for (auto& r : g_log) {
         if (hipEventSynchronize(r.b) != hipSuccess) return MFC_ERR_LAUNCH;
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
-        if (r.bucket >= 0 && r.bucket < MFC_PROF_BUCKETS) {
-            out->ms[r.bucket] += ms; out->flops[r.bucket] += r.flops; out->bytes[r.bucket] += r.bytes; out->launches[r.bucket] += 1;
+        int row = -1;
+        for (int i = 0; i < n && row < 0; ++i) if (!strcmp(out[i].name, r.name)) row = i;
+        if (row < 0 && n < cap) {
+            row = n++;
+            memset(&out[row], 0, sizeof(out[row]));
+            strncpy(out[row].name, r.name, sizeof(out[row].name) - 1);
         }
+        if (row >= 0) { out[row].ms += ms; out[row].flops += r.flops; out[row].bytes += r.bytes; out[row].launches += 1; }
         g_pool.push_back(r.a); g_pool.push_back(r.b);
     }
     g_log.clear();
-    return MFC_OK;
+    return n;
 }
 
 // ------------------------------------------------------------------ program interpreter

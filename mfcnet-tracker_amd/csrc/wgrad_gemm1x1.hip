@@ -218,7 +218,7 @@ int wgrad_gemm1x1_launch(const mfc_wgrad_desc* d, hipStream_t st) {
     if (g_mfc_prof_on) {
         const double flops = 2.0 * k.M * (double)k.Co16 * k.Ci16;
         const double bytes = (double)k.M * (k.Cin_p + k.Cout_p) * 2.0;
-        mfc_prof_before(st, 1 * 128 + 64 + 24, flops, bytes);       // weight-gradient family, bf16, slot 24 (wgrad_gemm1x1_kernel)
+        mfc_prof_before(st, "wgrad_gemm1x1_kernel", flops, bytes);
     }
     hipLaunchKernelGGL(wgrad_gemm1x1_kernel, dim3(k.co_blocks * k.ci_blocks * k.S), dim3(512), WG_LDS, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);

@@ -111,8 +111,8 @@ class LossDesc(C.Structure):
                 ("B", i32), ("nc", i32), ("H", i32), ("W", i32), ("w_nll", f32), ("w_jac", f32), ("grad_scale", f32)]
 
 
-class ProfResult(C.Structure):
-    _fields_ = [("ms", C.c_double * 256), ("flops", C.c_double * 256), ("bytes", C.c_double * 256), ("launches", C.c_int64 * 256)]
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 120), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", C.c_int64)]
 
 
 class RawOp(C.Structure):
@@ -178,7 +178,7 @@ def _load():
     lib.mfc_conv2d_layout.argtypes = [vp, vp]
     lib.mfc_set_flag.argtypes = [i32, i32]
     lib.mfc_prof_enable.argtypes = [i32]
-    lib.mfc_prof_collect.argtypes = [vp]
+    lib.mfc_prof_collect.argtypes = [vp, i32]
     if lib.mfc_op_size() != C.sizeof(Op):
         raise MfcError(f"mfc_op size mismatch: library {lib.mfc_op_size()} vs python mirror {C.sizeof(Op)}")
     return lib
@@ -217,3 +217,13 @@ def conv_layout(desc: ConvDesc) -> ConvLayout:
 
 def pack_job_fields(lay: ConvLayout) -> dict:
     return dict(KG=lay.KG, nchunks=lay.nchunks, NT16=lay.NT16, Yblocks=lay.Yblocks, nslots=lay.nslots, TAS=lay.TAS)
+
+
+def prof_collect(cap: int = 256):
+    """Rows of the event profiler as dicts {name, ms, flops, bytes, launches} (see mfc_prof_collect), largest total time first."""
+    arr = (ProfEntry * cap)()
+    n = lib.mfc_prof_collect(arr, cap)
+    if n < 0:
+        raise MfcError(f"mfc_prof_collect failed with status {n}")
+    rows = [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes, launches=arr[i].launches) for i in range(n)]
+    return sorted(rows, key=lambda r: -r["ms"])

@@ -69,6 +69,7 @@ class GradBucketReducer:
         self.works, self.ranges = [], []
         self._comm = None
         model.grad_bucket_hook = self._on_bucket
+        model._bucket_reducer = self            # engine.train_step finishes these all-reduces instead of reducing the arena again
 
     def _on_bucket(self, lo, hi):
         self.ranges.append((lo, hi))
@@ -104,5 +105,7 @@ class GradBucketReducer:
         return r
 
     def remove(self):
+        self.finish()
         self.model.grad_bucket_hook = None
+        self.model._bucket_reducer = None
 

@@ -25,6 +25,19 @@ def _forward(model, input, optflow, depth):
     return model(input)
 
 
+def reduce_gradients(model, world_size, group=None):
+    """The data-parallel exchange of a step: finish the per-bucket all-reduces a `dist.GradBucketReducer` started inside the
+    backward pass, or -- without one -- reduce the whole arena now.  SUM either way: `mfc_loss(global_batch=True)` already
+    normalised the logit gradients over the global batch."""
+    if world_size <= 1:
+        return
+    red = getattr(model, "_bucket_reducer", None)
+    if red is not None:
+        red.finish()
+    else:
+        allreduce_grads(model, world_size, group=group, average=False)
+
+
 def train_step(model, optimizer, input, mask, optflow=None, depth=None, loss_wts=(0.7, 0.3),
                class_weights=DEFAULT_CLASS_WEIGHTS, world_size=1, group=None):
     """One optimisation step; returns (output logits, acc) with acc[26:29] = (nll, soft_jaccard, total) on the device.
@@ -34,12 +47,7 @@ def train_step(model, optimizer, input, mask, optflow=None, depth=None, loss_wts
     output = _forward(model, input, optflow, depth)
     loss, acc = mfc_loss(output, mask, class_weights, loss_wts[0], loss_wts[1], global_batch=world_size > 1, group=group)
     loss.backward()
-    if world_size > 1:
-        red = getattr(model, "_bucket_reducer", None)
-        if red is not None:
-            red.finish()                # bucketed all-reduces started during the backward pass (dist.GradBucketReducer)
-        else:
-            allreduce_grads(model, world_size, group=group, average=False)
+    reduce_gradients(model, world_size, group)
     optimizer.step()
     return output.detach(), acc
 

@@ -49,8 +49,11 @@ class _LossFn(torch.autograd.Function):
         return dl * gtot, None, None, None, None, None
 
 
-def mfc_loss(logits, target, class_weights=DEFAULT_CLASS_WEIGHTS, w_nll=0.7, w_jac=0.3, global_batch=False, group=None):
-    """`global_batch=True`: evaluate the loss over all ranks' clips (see module docstring); `group` = process group."""
+def mfc_loss(logits, target, class_weights=DEFAULT_CLASS_WEIGHTS, w_nll=0.7, w_jac=0.3, global_batch=False, group=None,
+             check_labels=False):
+    """`global_batch=True`: evaluate the loss over all ranks' clips (see module docstring); `group` = process group.
+    Targets outside [0, num_classes) are ignored by the kernels and counted in acc[29] (nn.NLLLoss raises on them, loss.py:31-43);
+    `check_labels=True` reads that counter back (one host sync) and raises IndexError like the reference would."""
     if not logits.is_cuda:
         raise L.MfcError("mfc_loss runs on the GPU only")
     cw = torch.as_tensor(class_weights, dtype=torch.float32, device=logits.device)
@@ -61,4 +64,7 @@ def mfc_loss(logits, target, class_weights=DEFAULT_CLASS_WEIGHTS, w_nll=0.7, w_j
         import torch.distributed as dist
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             g = group if group is not None else True
-    return _LossFn.apply(logits, target, cw, float(w_nll), float(w_jac), g)
+    loss, acc = _LossFn.apply(logits, target, cw, float(w_nll), float(w_jac), g)
+    if check_labels and float(acc[29]) > 0:
+        raise IndexError(f"Target out of bounds: {int(acc[29])} label(s) outside [0, {logits.shape[1]})")
+    return loss, acc

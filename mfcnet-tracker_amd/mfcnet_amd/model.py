@@ -172,15 +172,18 @@ class HRNetMultiHIP(nn.Module):
     def _get_plan(self, B, H, W, has_flow, has_depth, need_bwd, device):
         from .plan import Plan
         base_tr = self.training if self.single else self.base_model.training
+        # the reference's default mode freezes the per-frame network (`param.requires_grad = False` for base_model,
+        # scripts/train_multiframe_detection.py:159-165): then its backward is not part of the program at all
+        frozen = need_bwd and not self.single and not any(p.requires_grad for p in self.base_model.parameters())
         key = (B, H, W, has_flow, has_depth, base_tr, self.multiframe_net.training, need_bwd,
-               self.compute_dtype, self.fuse_bn)
+               self.compute_dtype, self.fuse_bn, frozen)
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) >= 2:
                 self._plans.clear()
                 torch.cuda.empty_cache()
             plan = Plan(self, B, H, W, has_flow, has_depth, base_tr, self.multiframe_net.training,
-                        need_bwd, device)
+                        need_bwd, device, base_frozen=frozen)
             self._plans[key] = plan
         return plan
 
@@ -206,17 +209,30 @@ class HRNetMultiHIP(nn.Module):
         return plan.run_forward(frames, optflow, depth)
 
     def _run_backward(self, plan, gout):
-        params = [p for p in self.parameters()]
-        live = params[0].grad is not None
+        """Runs the backward program and exposes the flat gradient arena as the `.grad` of every parameter that requires one.
+        autograd semantics: a parameter whose `.grad` is still set (no zero_grad() since the last backward) ACCUMULATES; one
+        whose `.grad` is None gets a fresh gradient.  Parameters with requires_grad=False never get a `.grad` (and when the whole
+        per-frame network is frozen its backward is not even computed, see _get_plan)."""
+        named = list(self.named_parameters())
+        live = [(n, p) for n, p in named if p.requires_grad and p.grad is not None]
         if live and getattr(self, "grad_bucket_hook", None) is not None:
             raise L.MfcError("gradient accumulation across backward passes cannot be combined with a gradient-bucket hook "
                              "(the buckets are reduced while the pass runs): call zero_grad() before every backward")
-        old = self._G.clone() if live else None
+        old = None
+        if live:
+            old = self._G.clone()
+            if len(live) != sum(1 for _, p in named if p.requires_grad):
+                # mixed state: only the parameters that still hold a gradient accumulate
+                keep = torch.zeros_like(old)
+                for n, p in live:
+                    off = self._poff[n]
+                    keep[off:off + p.numel()] = old[off:off + p.numel()]
+                old = keep
         plan.run_backward(gout)
         if old is not None:
             self._G.add_(old)
-        for n, p in self.named_parameters():
-            if p.grad is None:
+        for n, p in named:
+            if p.requires_grad and p.grad is None:
                 off = self._poff[n]
                 p.grad = self._G[off:off + p.numel()].view(p.shape)
 

@@ -1,10 +1,21 @@
 """Fused Adam over the model's flat parameter arena.
 
-Same update rule and the same two learning-rate groups as the reference's
+Same update rule and the same learning-rate groups as the reference's
 `torch.optim.Adam([{base_model params, lr/T or lr/(100T)}, {multiframe_net params, lr}])`
 (scripts/train_multiframe_detection.py:128-151; default betas/eps, no weight decay), but one kernel
 launch per group over contiguous fp32 segments instead of 931 per-tensor updates.
-`torch.optim.Adam(model.parameters())` also works on the model (parameters are views of the arena).
+
+FlatAdam IS a `torch.optim.Optimizer`: `param_groups` holds one group per arena segment that has trainable
+parameters (name, params, lr, betas, eps), so the reference's `StepLR(optimizer, ...)`
+(train_multiframe_detection.py:152-157) and every other `lr_scheduler` drive it unchanged -- `step()` reads each
+group's current `lr`.  A segment whose parameters all have `requires_grad=False` gets no group and is never
+updated: with the per-frame network frozen (the reference's default mode, :159-165: `optim.Adam(
+model.multiframe_net.parameters())`) only the temporal head moves.  Frozen parameters inside a trainable segment
+see a zero gradient (their moments stay zero, so they do not move either).
+
+Checkpoints: `state_dict()` stores the two moment arenas as flat tensors (layout "flat-arena-v1"), not torch
+Adam's per-parameter dict, so the 'optimizer' entry of a file written with FlatAdam loads into FlatAdam only (and
+the reference's into `torch.optim.Adam`, which also works on this model: parameters are views of the arena).
 """
 from __future__ import annotations
 
@@ -13,44 +24,63 @@ import torch
 from . import _lib as L
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     def __init__(self, model, lr=1e-4, load_wts_base_model=False, betas=(0.9, 0.999), eps=1e-8):
         self.model = model
         T = model.num_frames
         base_lr = lr / (100.0 * T) if load_wts_base_model else lr / T
-        self.lrs = {"base_model": base_lr, "multiframe_net": lr}
-        self.betas, self.eps = betas, eps
+        lrs = {"base_model": base_lr, "multiframe_net": lr}
+        named = list(model.named_parameters())
+        groups = []
+        for name, (a, b) in model.flat_segments().items():
+            ps = [p for n, p in named if a <= model._poff[n] < b]
+            if any(p.requires_grad for p in ps):
+                groups.append({"params": ps, "lr": lrs[name], "name": name, "segment": (a, b)})
+        if not groups:
+            raise ValueError("FlatAdam: no parameter of the model requires a gradient")
+        super().__init__(groups, dict(lr=lr, betas=tuple(betas), eps=eps))
         self.step_count = 0
         self.m = torch.zeros_like(model._P)
         self.v = torch.zeros_like(model._P)
         self._arena = model._P
 
-    def zero_grad(self, set_to_none=True):
-        for p in self.model.parameters():
-            p.grad = None
+    @property
+    def lrs(self):
+        return {g["name"]: g["lr"] for g in self.param_groups}
 
-    def step(self, grad_scale: float = 1.0):
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
         mdl = self.model
         if mdl._P is not self._arena:
             raise L.MfcError("model was moved after the optimizer was built; rebuild FlatAdam")
         self.step_count += 1
         st = L.stream_ptr()
-        for name, (a, b) in mdl.flat_segments().items():
-            n = b - a
+        for g in self.param_groups:
+            a, b = g["segment"]
+            for p in g["params"]:
+                if not p.requires_grad:                 # frozen inside a trainable segment: zero gradient -> zero moments -> no update
+                    off = (p.data_ptr() - mdl._P.data_ptr()) // 4
+                    mdl._G[off:off + p.numel()].zero_()
             L.check(L.lib.mfc_adam_step(mdl._P.data_ptr() + 4 * a, mdl._G.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
-                                        self.v.data_ptr() + 4 * a, n, self.lrs[name], self.betas[0], self.betas[1], self.eps,
+                                        self.v.data_ptr() + 4 * a, b - a, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
                                         self.step_count, grad_scale, st), "mfc_adam_step")
+        return loss
 
     # ---- checkpointing (utils/model_utils.py:6-12 stores optimizer.state_dict() next to the model's) ----
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.m.detach().cpu().clone(), "exp_avg_sq": self.v.detach().cpu().clone(),
-                "lrs": dict(self.lrs), "betas": tuple(self.betas), "eps": self.eps, "layout": "flat-arena-v1"}
+                "lrs": dict(self.lrs), "betas": tuple(self.param_groups[0]["betas"]), "eps": self.param_groups[0]["eps"],
+                "layout": "flat-arena-v1"}
 
     def load_state_dict(self, sd):
         if sd.get("layout") != "flat-arena-v1" or sd["exp_avg"].numel() != self.m.numel():
-            raise L.MfcError("optimizer state does not belong to a FlatAdam of this model")
+            raise L.MfcError("optimizer state does not belong to a FlatAdam of this model (torch.optim.Adam state dicts load "
+                             "into torch.optim.Adam, which also works on this model)")
         self.step_count = int(sd["step"])
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
-        self.lrs.update(sd["lrs"])
-        self.betas, self.eps = tuple(sd["betas"]), float(sd["eps"])
+        for g in self.param_groups:
+            if g["name"] in sd["lrs"]:
+                g["lr"] = sd["lrs"][g["name"]]
+            g["betas"], g["eps"] = tuple(sd["betas"]), float(sd["eps"])

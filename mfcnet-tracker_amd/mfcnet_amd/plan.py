@@ -104,6 +104,7 @@ class ConvInfo:
     dgrad: List = field(default_factory=list)     # data-gradient launch descriptors (1 for stride 1, 4 parity classes for stride 2)
     dwp: int = 0
     wg: Optional[object] = None                   # weight-gradient launch descriptor (x / dy pointers filled at backward emission)
+    fwd: Optional[object] = None                  # the forward launch descriptor
     slice_bytes: int = 0                          # one partial-sum slice of the packed gradient image
     unpack: Optional[dict] = None                 # unpack job fields (source / slice count are set with the launch)
 
@@ -132,8 +133,15 @@ class _Ops(list):
 
 
 class Plan:
-    def __init__(self, model, B, H, W, has_flow, has_depth, base_training, head_training, need_backward, device):
+    def __init__(self, model, B, H, W, has_flow, has_depth, base_training, head_training, need_backward, device,
+                 base_frozen=False, dry=False):
+        """dry=True: plan only (descriptors, geometry, sizes) with placeholder addresses -- no device memory, nothing runnable;
+        works without a GPU (tests enumerate the launches of a configuration this way)."""
         self.m = model
+        # base_frozen: no parameter of the per-frame network requires a gradient (the reference's default mode,
+        # scripts/train_multiframe_detection.py:159-165): the backward program stops at the temporal head's input -- no
+        # head-gather adjoint, no data gradient of the 11x11 convolution, nothing of the per-frame network
+        self.base_frozen = bool(base_frozen) and not getattr(model, "single", False)
         self.B, self.H, self.W = B, H, W
         self.T, self.nc, self.width = model.num_frames, model.num_classes, model.width
         self.basic = model.basic
@@ -154,7 +162,16 @@ class Plan:
         self.mask_bits = getattr(model, "relu_mask_bits", True)     # 1-bit ReLU masks for the BatchNorm backward (bf16)
         self.lanes = getattr(model, "parallel_branches", True)      # branch-parallel lanes of the program (include/mfcnet_hip.h, mfc_op.lane)
         self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc")}
-        self._build()                       # dry pass: sizes
+        self.dry = dry
+        self._build()                       # sizing pass
+        if dry:
+            base = 1 << 30
+            for a in self.arenas.values():
+                a.base = base
+                base += rup(a.size, 1 << 20) + (1 << 20)
+            self._build()
+            self.bytes_total = sum(a.size for a in self.arenas.values())
+            return
         for a in self.arenas.values():
             a.buf = torch.empty(max(a.size, 256) + 256, dtype=torch.uint8, device=device)
             a.base = rup(a.buf.data_ptr(), 256)
@@ -320,6 +337,7 @@ class Plan:
                        Ho, Wo, y.Cp, cout, Ho, Wo, k, k, -pad, -pad, stride, 1, 1, 0, 0,
                        1 if x.relu else 0, xt.ipg, 0, 0, 0)
         ci = self.conv_info(d, xt, y, wname, cout, xt.C, k, stride, bias, x.bn.coef if x.bn else 0, 1 if x.relu else 0)
+        ci.fwd = d
         self.fwd.append((L.OP_CONV, d))
         self.ops.append(("conv", x, y, ci, bn))
         if bn:
@@ -382,10 +400,11 @@ class Plan:
             r.i[0:7] = [self.dtype, B, 3, H, W, x0.Cp, 0]
             self.fwd.append((L.OP_NCHW2NHWC, r))
         logits = self._hrnet(Act(x0))
+        self.n_base_ops = len(self.ops)               # forward graph nodes [0, n_base_ops) belong to the per-frame network
         # ---- head input: x4 up-sample + temporal concat (+flow, +depth, +warp)
         basic_warp = self.basic and self.has_flow
         cin = head_in_channels(self.basic, nc, T, self.has_flow, self.has_depth)
-        xh = self.tensor(B, H, W, cin, B, "head_in")
+        xh = self.tensor(B, H, W, cin, B, "head_in", needs_grad=not self.base_frozen)
         hd = L.HeadDesc()
         hd.logits, hd.xh = logits.ptr, xh.ptr
         for i, p in enumerate(self.in_flow):
@@ -547,8 +566,11 @@ class Plan:
         E, Cs = self.E, None
         self._wg_pending, self._wg_arrays = {}, []
         self._ready = {}
-        for op, lane in zip(reversed(self.ops), reversed(self.ops.lanes)):
+        n_ops = len(self.ops)
+        for ridx, (op, lane) in enumerate(zip(reversed(self.ops), reversed(self.ops.lanes))):
             kind = op[0]
+            if self.base_frozen and (n_ops - 1 - ridx < self.n_base_ops or kind == "head"):
+                continue                # frozen per-frame network: its gradients are neither needed nor computed
             if lane != self.cur_lane:
                 # leaving a lane: what is still queued there is launched first (from the lane that produced its inputs; after a
                 # parallel section the first serial record joins the side lanes before anything runs)
@@ -700,6 +722,8 @@ class Plan:
         # eval-mode BatchNorm finalizes read only the running statistics: one table launch in front of the first convolution
         # instead of one one-block launch between every conv and its consumer
         ev = [rec for rec in self.fwd if rec[0] == L.OP_BNFIN and not rec[1].training]
+        if any(rec[1].G > 8 or rec[1].G < 1 for rec in ev):
+            raise L.MfcError("BatchNorm finalize table: a row has more than 8 statistic groups (num_frames > 8 is not supported)")
         if len(ev) > 1 and getattr(self.m, "batch_eval_bnfin", True):
             tab = (L.BnFinDesc * len(ev))(*[rec[1] for rec in ev])
             self._bnfin_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)

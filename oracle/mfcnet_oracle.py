@@ -245,7 +245,14 @@ class Net:
     """Holds the state dict (params require grad) and evaluates the reference graph functionally."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], model_type: str = "HRNetMulti-Large", width: int = 48,
-                 num_classes: int = 5, T: int = 3, optflow: bool = False, depth: bool = False):
+                 num_classes: int = 5, T: int = 3, optflow: bool = False, depth: bool = False, store_dtype=None):
+        """store_dtype=torch.bfloat16: FORWARD-ONLY emulation of the MI355X throughput mode's storage rounding on top of the
+        pinned fp32 graph -- every tensor the HIP plan materialises in bf16 is rounded to bf16 where the plan rounds it (conv
+        operands: input and weights; conv outputs, after the BatchNorm statistics were taken from the fp32 accumulators; the
+        outputs of the residual / fuse-layer / transition / concat sums), everything else (accumulation, BatchNorm
+        coefficients, bilinear weights, biases) stays fp32.  It is the checker for the bf16 kernels' arithmetic: against it
+        only summation order differs, not the 2^-8 storage rounding itself."""
+        self.store_dtype = store_dtype
         self.model_type, self.width, self.nc, self.T = model_type, width, num_classes, T
         self.optflow, self.depth = optflow, depth
         self.table = mfcnet_table(model_type, width, num_classes, T, optflow, depth)
@@ -277,18 +284,35 @@ class Net:
             self.sd[n].grad = None
 
     # -- primitive layers ---------------------------------------------------
-    def _conv(self, x, name, stride=1, pad=0):
-        return F.conv2d(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"), stride=stride, padding=pad)
+    def _q(self, t):
+        """storage rounding of the emulated throughput mode (identity in the pinned fp32 mode)"""
+        sdt = getattr(self, "store_dtype", None)
+        return t if sdt is None else t.to(sdt).to(torch.float32)
+
+    def _conv(self, x, name, stride=1, pad=0, raw=False):
+        y = F.conv2d(self._q(x), self._q(self.sd[name + ".weight"]), self.sd.get(name + ".bias"), stride=stride, padding=pad)
+        return y if raw else self._q(y)
 
     def _bn(self, x, name, training):
         s = self.sd
         if training:
             s[name + ".num_batches_tracked"] += 1     # torch BatchNorm bookkeeping; momentum is fixed (0.1)
-        return F.batch_norm(x, s[name + ".running_mean"], s[name + ".running_var"], s[name + ".weight"],
+        if training and getattr(self, "store_dtype", None) is not None:
+            # emulated throughput mode: the statistics come from the fp32 accumulators, the normalisation reads the rounded tensor
+            with torch.no_grad():
+                mean = x.mean(dim=(0, 2, 3))
+                var = x.var(dim=(0, 2, 3), unbiased=False)
+                n = x.numel() // x.shape[1]
+                s[name + ".running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
+                s[name + ".running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * n / max(n - 1, 1))
+            scale = s[name + ".weight"] / torch.sqrt(var + BN_EPS)
+            shift = s[name + ".bias"] - mean * scale
+            return self._q(x) * scale[None, :, None, None] + shift[None, :, None, None]
+        return F.batch_norm(self._q(x), s[name + ".running_mean"], s[name + ".running_var"], s[name + ".weight"],
                             s[name + ".bias"], training, BN_MOMENTUM, BN_EPS)
 
     def _cbr(self, x, conv, bn, k, stride, relu, training):
-        y = self._bn(self._conv(x, conv, stride, k // 2), bn, training)
+        y = self._bn(self._conv(x, conv, stride, k // 2, raw=True), bn, training)
         return F.relu(y) if relu else y
 
     # -- HRNet, hrnet.py:425-476 ---------------------------------------------
@@ -305,21 +329,21 @@ class Net:
             o = self._cbr(o, q + "conv3", q + "bn3", 1, 1, False, tr)
             if b == 0:
                 res = self._cbr(x, q + "downsample.0", q + "downsample.1", 1, 1, False, tr)
-            x = F.relu(o + res)
+            x = self._q(F.relu(o + res))
 
         def transition(name, ys, pre, cur):                            # :434-461, 353-389
             out = []
             for i, c in enumerate(cur):
                 if i < len(pre):
                     if c != pre[i]:
-                        out.append(self._cbr(ys[i], f"{p}{name}.{i}.0", f"{p}{name}.{i}.1", 3, 1, True, tr))
+                        out.append(self._q(self._cbr(ys[i], f"{p}{name}.{i}.0", f"{p}{name}.{i}.1", 3, 1, True, tr)))
                     else:
                         out.append(ys[i])
                 else:
                     v = ys[-1]
                     for j in range(i + 1 - len(pre)):
                         v = self._cbr(v, f"{p}{name}.{i}.{j}.0", f"{p}{name}.{i}.{j}.1", 3, 2, True, tr)
-                    out.append(v)
+                    out.append(self._q(v))
             return out
 
         def module(q, xs):                                              # HighResolutionModule.forward :238-262
@@ -331,7 +355,7 @@ class Net:
                     r = f"{q}branches.{i}.{b}."
                     o = self._cbr(v, r + "conv1", r + "bn1", 3, 1, True, tr)
                     o = self._cbr(o, r + "conv2", r + "bn2", 3, 1, False, tr)
-                    v = F.relu(o + v)
+                    v = self._q(F.relu(o + v))
                 xs[i] = v
             outs = []
             for i in range(nb):
@@ -348,7 +372,7 @@ class Net:
                         for k in range(i - j):
                             term = self._cbr(term, f"{r}{k}.0", f"{r}{k}.1", 3, 2, k != i - j - 1, tr)
                     y = term if y is None else y + term
-                outs.append(F.relu(y))
+                outs.append(self._q(F.relu(y)))
             return outs
 
         ys = transition("transition1", [x], [256], W[:2])
@@ -360,8 +384,8 @@ class Net:
         for m in range(3):
             ys = module(f"{p}stage4.{m}.", ys)
         h, w = ys[0].shape[-2:]                                         # :464-469
-        cat = torch.cat([ys[0]] + [F.interpolate(v, size=(h, w), mode="bilinear", align_corners=False)
-                                   for v in ys[1:]], 1)
+        cat = self._q(torch.cat([ys[0]] + [F.interpolate(v, size=(h, w), mode="bilinear", align_corners=False)
+                                           for v in ys[1:]], 1))
         o = self._cbr(cat, p + "last_layer.0", p + "last_layer.1", 1, 1, True, tr)     # :470, 334-351
         o = self._conv(o, p + "last_layer.3")
         return F.interpolate(o, size=(o.shape[2] * 4, o.shape[3] * 4), mode="bilinear", align_corners=False)  # :473-474
@@ -426,7 +450,8 @@ class SingleNet(Net):
     hrnet_table without prefix).  forward(x) = hrnet.py:425-476 on ONE [B,3,H,W] tensor; the caller applies log_softmax
     (scripts/train_toolpose_segmentation.py:162-163)."""
 
-    def __init__(self, sd, width: int = 48, num_classes: int = 5):
+    def __init__(self, sd, width: int = 48, num_classes: int = 5, store_dtype=None):
+        self.store_dtype = store_dtype            # see Net.__init__
         self.model_type, self.width, self.nc, self.T = "HRNet", width, num_classes, 1
         self.optflow, self.depth = False, False
         self.table = hrnet_table(width, num_classes, "")
@@ -443,7 +468,7 @@ class SingleNet(Net):
         self.head_training = True
 
     def forward(self, x):
-        return self.hrnet(x, p="")
+        return self._q(self.hrnet(x, p=""))       # (the x4 up-sampled map is the output tensor: stored, hence rounded, in the emulated mode)
 
     __call__ = forward
 

@@ -18,7 +18,11 @@ def main():
     import mfcnet_amd as mfc
     from mfcnet_amd.dist import GradBucketReducer, allreduce_grads, broadcast_params
     torch.manual_seed(7)
-    model = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, width=16, compute_dtype="fp32").cuda().train()
+    # eval-mode BatchNorm (running statistics): no statistic atomics, so the two orders must agree to fp32 rounding of the all-reduce
+    # itself -- a bucket reduced before its gradients were final would be off by O(1)
+    model = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, width=16, compute_dtype="fp32").cuda().eval()
+    with torch.no_grad():
+        model._RS.uniform_(0.5, 1.5)          # (running_mean / running_var: any positive values)
     broadcast_params(model)
     g = torch.Generator().manual_seed(100 + rank)
     frames = [torch.randn(2, 3, 64, 96, generator=g).cuda() for _ in range(3)]
@@ -44,11 +48,20 @@ def main():
     rel = float((g1 - g2).double().norm() / g2.double().norm())
     # per bucket as well: a bucket reduced too early would be off by O(1) on its own range only
     worst = max(float((g1[lo:hi] - g2[lo:hi]).double().norm() / (g2[lo:hi].double().norm() + 1e-30)) for lo, hi in ranges)
-    ok = abs(l1 - l2) < 1e-4 and rel < 6e-2 and worst < 0.2 and float(g2.abs().max()) > 0 and len(ranges) >= 2
+    ok = abs(l1 - l2) < 1e-5 and rel < 1e-4 and worst < 1e-4 and float(g2.abs().max()) > 0 and len(ranges) >= 2
+    # train_step with the reducer installed: it must FINISH the bucket all-reduces, not reduce the arena a second time
+    red2 = GradBucketReducer(model, average=False)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    mfc.train_step(model, opt, frames, mask, world_size=2)
+    torch.cuda.synchronize()
+    g3 = model._G.detach().clone()
+    red2.remove()
+    rel3 = float((g3 - g2).double().norm() / g2.double().norm())
+    ok = ok and rel3 < 1e-4 and red2.works == []
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print(f"OVERLAP_CHECK ok={int(flag.item())} rel={rel:.3e} worst_bucket={worst:.3e} loss={l1:.6f}/{l2:.6f} buckets={len(ranges)}", flush=True)
+        print(f"OVERLAP_CHECK ok={int(flag.item())} rel={rel:.3e} worst_bucket={worst:.3e} loss={l1:.6f}/{l2:.6f} buckets={len(ranges)} train_step_rel={rel3:.3e}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if flag.item() == 1.0 else 1)
 

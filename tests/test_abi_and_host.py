@@ -43,7 +43,7 @@ def test_ctypes_mirrors_match_c_struct_sizes(L):
                "mfc_unpack_job": L.UnpackJob, "mfc_bnfin_desc": L.BnFinDesc, "mfc_view": L.View, "mfc_combine_desc": L.CombineDesc,
                "mfc_bnbwd_desc": L.BnBwdDesc, "mfc_bnbwdfin_desc": L.BnBwdFinDesc, "mfc_maskadd_desc": L.MaskAddDesc,
                "mfc_headgather_desc": L.HeadDesc, "mfc_loss_desc": L.LossDesc, "mfc_conv_layout": L.ConvLayout,
-               "mfc_prof_result": L.ProfResult}
+               "mfc_prof_entry": L.ProfEntry}
     prog = '#include "mfcnet_hip.h"\n#include <stdio.h>\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in structs) + "return 0;}"
     with tempfile.TemporaryDirectory() as td:
@@ -151,3 +151,27 @@ def test_gradient_buckets_partition_the_backward_program():
     # buckets complete from the end of the arena (the head is first in backward)
     assert pl.bwd_segments[0][2] == m._np
 
+
+
+def test_dry_plan_enumerates_the_benchmarked_launches_without_a_gpu():
+    """Plan(dry=True) lays the whole step out with placeholder addresses (no device memory): the geometry search of every launch of
+    BASELINE configs[2] runs on the host, and tests/test_gpu_plan_kernels.py replays exactly these descriptors on the GPU."""
+    import mfcnet_amd as mfc
+    from mfcnet_amd import _lib
+    from mfcnet_amd.plan import Plan
+    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, width=32, compute_dtype="bf16").train()
+    pl = Plan(m, 8, 480, 640, False, False, True, True, True, torch.device("cpu"), dry=True)
+    convs = [op[3] for op in pl.ops if op[0] == "conv"]
+    assert len(convs) == 311                                         # SURVEY.md appendix B: 307 base + 4 head convolutions
+    assert all(ci.fwd is not None and ci.wg is not None for ci in convs)
+    assert sum(1 for ci in convs if not ci.dgrad) == 1               # only the stem conv (its input are the frames) has no data gradient
+    for ci in convs[:20]:
+        lay = _lib.conv_layout(ci.fwd)
+        assert lay.bytes > 0 and lay.NW in (4, 8)
+        assert _lib.wgrad_parts(ci.wg) >= 1
+    # frozen per-frame network (the reference's default mode): the backward is the temporal head's only
+    for p in m.base_model.parameters():
+        p.requires_grad = False
+    plf = Plan(m, 8, 480, 640, False, False, False, True, True, torch.device("cpu"), base_frozen=True, dry=True)
+    assert len(plf.bwd) < 40 and not any(r[0] == _lib.OP_HEAD_BWD for r in plf.bwd)
+    assert len(pl.bwd) > 1000

@@ -35,11 +35,17 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "frames/s" and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
-    rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
-        assert k in rf, k
-    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    for rf in (d["roofline"], d["roofline_conv"]):
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"):
+            assert k in rf, k
+        assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # `roofline` is the row with the largest total time of the profiled step, whatever family it belongs to
+    top = d["roofline"]["top5"]
+    assert top[0]["kernel"] == d["roofline"]["kernel"] and all(top[i]["ms_per_step"] >= top[i + 1]["ms_per_step"] for i in range(len(top) - 1))
+    assert d["roofline_conv"]["kernel"].startswith("conv_igemm_kernel<")
+    assert d["roofline"]["profiled_step_streams"].startswith("serial")
     assert 0.0 < d["config"]["final_loss"] < 20.0
+    assert d["config"]["launcher"] == "bench.py" and d["config"]["ranks"] == 1
 
 
 def test_bench_two_ranks_share_the_gpu_over_gloo():
@@ -53,6 +59,23 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 4 * 3 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]
     assert 0.0 < d["config"]["final_loss"] < 20.0
+    assert d["config"]["launcher"] == "external"
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (the driver's form, no torchrun): the parent starts two ranks before touching the GPU and relays
+    rank 0's line, which must report two ranks; a launcher whose world size disagrees with --gpus is refused."""
+    _need_gpu()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + SMALL,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["launcher"] == "bench.py" and d["config"]["backend"] == "gloo"
+    assert d["config"]["global_batch"] == 4 and 0.0 < d["config"]["final_loss"] < 20.0
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
 
 
 def test_overlapped_bucket_allreduce_equals_the_plain_order():

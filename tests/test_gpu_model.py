@@ -139,34 +139,113 @@ def test_state_dict_roundtrip_and_errors(mfc):
         m([t.cpu() for t in x])
 
 
-def test_bf16_mode_tracks_fp32(mfc):
-    """Throughput mode: bf16 storage / MFMA, fp32 accumulate + statistics.  Not a 1e-3 claim: bf16 rounding
-    (2^-8 relative per stored activation) through ~300 layers; eval mode is held to 5 % of the logit scale, the
-    train step (chaotic at fp32 already, see module docstring) to loss / gradient-direction agreement."""
-    cfg = dict(name="bf16case", model_type="HRNetMulti-Large", T=3, optflow=False, depth=False, B=4, H=128, W=192, mode="train")
+BF16_EVAL_TOL = 0.02        # of the logit scale; measured values are printed (bf16 storage rounding itself is NOT in this number)
+
+
+def _bf16_vs_storage_oracle(mfc, cfg, width, single=False):
+    """HIP bf16 (throughput mode) eval logits against the CPU oracle run with the SAME storage rounding (oracle `store_dtype=bfloat16`:
+    every tensor the plan materialises is rounded to bf16 where the plan rounds it).  What is left between the two is fp32 summation
+    order plus the rare bf16 rounding flips it causes (one flip = 2^-8 of one activation), so the bound is tight: max-abs <= 2 % of the
+    logit scale and mean-abs <= 0.2 %, where bf16 vs the fp32 oracle differs by several per cent."""
+    from oracle import mfcnet_oracle as O
     frames, flows, depths, mask = case_inputs(cfg)
-    outs = {}
-    for dt in ("fp32", "bf16"):
-        m = build(mfc, cfg, dtype=dt)
-        m.eval()
-        with torch.no_grad():
-            ye = m(dev(frames)).cpu()
-        m.train()
-        y = m(dev(frames))
-        loss, _ = mfc.mfc_loss(y, mask.cuda())
-        loss.backward()
-        outs[dt] = (ye, y.detach().cpu(), float(loss), m.base_model.last_layer[3].weight.grad.clone().cpu(),
-                    m.multiframe_net.multiframe_net[0].weight.grad.clone().cpu())
-    e32, y32, l32, g32, h32 = outs["fp32"]
-    e16, y16, l16, g16, h16 = outs["bf16"]
-    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))
-    print("bf16 vs fp32: eval max diff", float((e16 - e32).abs().max()), "of scale", float(e32.abs().max()),
-          "| train logits cos", cos(y16, y32), "loss", l16, l32, "grad cos", cos(g16, g32), cos(h16, h32))
-    assert float((e16 - e32).abs().max()) < 0.05 * float(e32.abs().max())      # deterministic (eval) path: tight
-    # train mode is chaotic already at fp32 (module docstring): bf16 rounding decorrelates individual activations, so only
-    # aggregate agreement is asserted here
-    assert cos(y16, y32) > 0.8 and abs(l16 - l32) < 0.02
-    assert cos(h16, h32) > 0.6 and bool(torch.isfinite(g16).all())
+    if single:
+        sd = O.hashed_state(O.hrnet_table(width, 5, ""))
+        net = O.SingleNet(sd, width, 5, store_dtype=torch.bfloat16).eval()
+        m = mfc.HighResolutionNetHIP(num_classes=5, width=width, compute_dtype="bf16")
+        args_o, args_m = (frames[0],), (frames[0].cuda(),)
+    else:
+        sd = O.hashed_state(O.mfcnet_table(cfg["model_type"], width, 5, cfg["T"], cfg["optflow"], cfg["depth"]))
+        net = O.Net(sd, cfg["model_type"], width, 5, cfg["T"], cfg["optflow"], cfg["depth"], store_dtype=torch.bfloat16).eval()
+        cls = mfc.HRNetMultiLarge if "Large" in cfg["model_type"] else mfc.HRNetMultiBasic
+        m = cls(num_classes=5, num_frames=cfg["T"], pretrained=False, width=width, compute_dtype="bf16",
+                optflow_inputs=cfg["optflow"], depth_inputs=cfg["depth"])
+        args_o, args_m = (frames,), (dev(frames),)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        ref = net(*args_o, **({} if single else dict(optflow=flows, depth=depths)))
+        y = m(*args_m, **({} if single else dict(optflow=dev(flows), depth=dev(depths)))).cpu()
+    scale = float(ref.abs().max())
+    mx, mean = float((y - ref).abs().max()), float((y - ref).abs().mean())
+    print(f"bf16 vs bf16-storage oracle [{cfg['name']} w{width}]: max {mx:.3e} mean {mean:.3e} of scale {scale:.3e}")
+    assert mx <= BF16_EVAL_TOL * scale and mean <= 0.1 * BF16_EVAL_TOL * scale, (mx, mean, scale)
+    return m, net
+
+
+def test_bf16_benchmarked_shape_eval_vs_storage_oracle(mfc):
+    """BASELINE.json configs[2]'s shape and dtype (T=3, B=8, 480x640, HRNet-w32, bf16): the geometries bench.py times."""
+    cfg = dict(name="bench_w32", model_type="HRNetMulti-Large", T=3, optflow=False, depth=False, B=8, H=480, W=640, mode="eval")
+    _bf16_vs_storage_oracle(mfc, cfg, 32)
+
+
+def test_bf16_single_frame_w32_eval_vs_storage_oracle(mfc):
+    """BASELINE.json configs[1]: single-frame HRNet-w32, forward only, B=8, 480x640, bf16 (`bench.py --single --fwd-only`)."""
+    cfg = dict(name="single_w32", model_type="HRNet", T=1, optflow=False, depth=False, B=8, H=480, W=640, mode="eval")
+    _bf16_vs_storage_oracle(mfc, cfg, 32, single=True)
+
+
+def test_bf16_small_shapes_vs_storage_oracle_and_fp32(mfc):
+    """Throughput mode on a small clip, all inputs (flow + depth), W48: eval logits against the bf16-storage oracle (tight), and the
+    train-mode forward -- batch statistics from the fp32 accumulators, normalisation of the rounded tensor -- against the same oracle
+    in train mode.  Train mode is chaotic already at fp32 (module docstring), so that bound is looser; gradients in bf16 are pinned
+    per kernel at the benchmarked shapes (tests/test_gpu_plan_kernels.py), here they are only checked for sanity against fp32."""
+    cfg = dict(name="bf16case", model_type="HRNetMulti-Large", T=3, optflow=True, depth=True, B=4, H=128, W=192, mode="train")
+    m, net = _bf16_vs_storage_oracle(mfc, cfg, 48)
+    frames, flows, depths, mask = case_inputs(cfg)
+    net.train()
+    with torch.no_grad():
+        ref = net(frames, optflow=flows, depth=depths)
+    m.train()
+    y = m(dev(frames), optflow=dev(flows), depth=dev(depths))
+    loss, _ = mfc.mfc_loss(y, mask.cuda())
+    loss.backward()
+    from oracle import mfcnet_oracle as O
+    lref, _ = O.total_loss(ref, mask, 5)
+    scale = float(ref.abs().max())
+    mx, mean = float((y.detach().cpu() - ref).abs().max()), float((y.detach().cpu() - ref).abs().mean())
+    print(f"bf16 train-mode forward vs bf16-storage oracle: max {mx:.3e} mean {mean:.3e} of scale {scale:.3e}; loss {float(loss):.5f} vs {float(lref):.5f}")
+    assert mx <= 0.1 * scale and mean <= 0.01 * scale and abs(float(loss.detach()) - float(lref)) < 5e-3
+    g16 = m.multiframe_net.multiframe_net[0].weight.grad.clone().cpu()
+    m32 = build(mfc, cfg, dtype="fp32")
+    m32.train()
+    l32, _ = mfc.mfc_loss(m32(dev(frames), optflow=dev(flows), depth=dev(depths)), mask.cuda())
+    l32.backward()
+    g32 = m32.multiframe_net.multiframe_net[0].weight.grad.cpu()
+    cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    print("bf16 vs fp32 head-gradient cosine", cos, "loss", float(loss), float(l32))
+    assert cos > 0.6 and bool(torch.isfinite(m._G).all()) and abs(float(loss.detach()) - float(l32.detach())) < 0.02
+
+
+def test_t5_720x960_fp32_training_step_vs_oracle(mfc):
+    """BASELINE.json configs[4]'s shape (T=5, HRNet-W48, 720x960; odd 23x30 level) as ONE fp32 training step, B=1: logits, loss and
+    sentinel gradients against the CPU oracle (the eval-mode forward of this shape is covered below with flow + depth)."""
+    from oracle import mfcnet_oracle as O
+    T, H, W = 5, 720, 960
+    cfg = dict(name="t5_720_train", model_type="HRNetMulti-Large", T=T, optflow=False, depth=False, B=1, H=H, W=W, mode="train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    sd = case_state(cfg)
+    net = O.Net(sd, cfg["model_type"], 48, 5, T).train()
+    ref = net(frames)
+    lref, _ = O.total_loss(ref, mask, 5)
+    lref.backward()
+    m = build(mfc, cfg)
+    m.train()
+    y = m(dev(frames))
+    loss, _ = mfc.mfc_loss(y, mask.cuda())
+    loss.backward()
+    assert float((y.detach().cpu() - ref.detach()).abs().max()) <= ATOL
+    assert abs(float(loss.detach()) - float(lref.detach())) < 1e-4
+    named = dict(m.named_parameters())
+    for p in ("multiframe_net.multiframe_net.0.weight", "multiframe_net.multiframe_net.9.weight", "base_model.last_layer.3.weight",
+              "base_model.stage4.2.branches.3.3.conv2.weight", "base_model.stage3.1.fuse_layers.2.0.0.0.weight", "base_model.conv1.weight"):
+        g, gr = named[p].grad.cpu(), net.sd[p].grad
+        assert abs(float(g.double().norm()) - float(gr.double().norm())) <= 2e-2 * float(gr.double().norm()) + 1e-6, p
+        assert rel_l2(g.numpy(), gr.numpy()) < GRAD_RTOL, p
+    bn = "base_model.stage4.0.branches.3.0.bn1"
+    st = m.state_dict()
+    np.testing.assert_allclose(st[bn + ".running_mean"].cpu().numpy(), net.sd[bn + ".running_mean"].numpy(), atol=5e-5)
+    assert int(st[bn + ".num_batches_tracked"]) == T
 
 
 def test_width32_matches_oracle(mfc):
@@ -468,3 +547,56 @@ def test_bucketed_backward_hook_covers_the_arena(mfc):
     assert seen[0][1] == m._np                                      # the temporal head's bucket is final first
     for lo, hi, g in snaps:
         assert rel_l2(g.cpu().numpy(), ref[lo:hi].cpu().numpy()) < GRAD_RTOL
+
+
+def test_head_only_training_three_steps_vs_oracle(mfc):
+    """The reference's default mode (scripts/train_multiframe_detection.py:159-165): base_model frozen (`requires_grad = False`, eval-mode
+    BatchNorm), `optim.Adam(model.multiframe_net.parameters())`.  Three optimisation steps against the CPU oracle run the same way:
+    losses per step, head parameters after the last step; the per-frame network gets no gradient, does not move, and its backward
+    is not part of the program (a handful of records instead of ~1500)."""
+    from oracle import mfcnet_oracle as O
+    from mfcnet_amd import _lib as L
+    cfg, _ = load_case("large_flow_headonly")
+    frames, flows, depths, mask = case_inputs(cfg)
+    sd = case_state(cfg)
+    net = O.Net(sd, cfg["model_type"], 48, 5, cfg["T"], cfg["optflow"], cfg["depth"]).train(base=False, head=True)
+    opt_o = torch.optim.Adam(net.params("multiframe_net."), lr=1e-3)
+    m = build(mfc, cfg)
+    set_mode(m, "headonly")
+    for p in m.base_model.parameters():
+        p.requires_grad = False
+    opt = torch.optim.Adam(m.multiframe_net.parameters(), lr=1e-3)
+    base_before = m._P[:m._n_base].clone()
+    for step in range(3):
+        net.zero_grad()
+        yo = net(frames, optflow=flows, depth=depths)
+        lo, _ = O.total_loss(yo, mask, 5)
+        lo.backward()
+        opt_o.step()
+        opt.zero_grad()
+        y = m(dev(frames), optflow=dev(flows), depth=dev(depths))
+        loss, _ = mfc.mfc_loss(y, mask.cuda())
+        loss.backward()
+        assert float((y.detach().cpu() - yo.detach()).abs().max()) <= (1 + step) * ATOL, step
+        assert abs(float(loss.detach()) - float(lo.detach())) < 2e-4 * (1 + step), step
+        for p in ("multiframe_net.multiframe_net.0.weight", "multiframe_net.multiframe_net.9.weight", "multiframe_net.multiframe_net.4.bias"):
+            g, go = dict(m.named_parameters())[p].grad.cpu(), net.sd[p].grad
+            assert float((g - go).norm() / go.norm()) < GRAD_RTOL, (step, p)
+        assert all(p.grad is None for p in m.base_model.parameters())
+        opt.step()
+    plan = next(iter(m._plans.values()))
+    assert plan.base_frozen and len(plan.bwd_prog) < 40
+    assert not any(op.kind == L.OP_HEAD_BWD for op in plan.bwd_prog)
+    assert torch.equal(m._P[:m._n_base], base_before)
+    for p in ("multiframe_net.multiframe_net.0.weight", "multiframe_net.multiframe_net.9.weight"):
+        a, b = dict(m.named_parameters())[p].detach().cpu(), net.sd[p].detach()
+        assert float((a - b).abs().max()) < 3 * 2.1e-3 * 0.5, p          # three Adam steps of lr 1e-3 (each moves a parameter by <= lr)
+        assert float((a - b).norm() / (b - sd[p]).norm()) < 0.1, p         # ... and the UPDATE itself agrees to 10 %
+    # FlatAdam in the same mode: only the head segment has a group
+    fa = mfc.FlatAdam(m, lr=1e-4)
+    assert [g["name"] for g in fa.param_groups] == ["multiframe_net"]
+    fa.zero_grad()
+    loss, _ = mfc.mfc_loss(m(dev(frames), optflow=dev(flows), depth=dev(depths)), mask.cuda())
+    loss.backward()
+    fa.step()
+    assert torch.equal(m._P[:m._n_base], base_before)

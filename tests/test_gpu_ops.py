@@ -495,6 +495,34 @@ def test_loss_fwd_bwd(M):
     assert relerr(lg.grad.cpu(), logits.grad) < 1e-4
 
 
+def test_loss_out_of_range_labels_are_ignored_and_counted(M):
+    """A target outside [0, nc) (a 255 'ignore' value, a corrupt mask) must not index class_w / logits out of bounds (nn.NLLLoss
+    raises on it, src/loss.py:31-43): the kernels drop those pixels from the NLL term, count them in acc[29], and
+    mfc_loss(check_labels=True) raises like the reference.  In-range pixels keep their exact contribution: the loss equals the
+    reference's NLL with ignore_index on the bad pixels (+ the Jaccard term with those pixels in no class)."""
+    mfc, L, ops = M
+    import torch.nn.functional as F
+    B, nc, H, W = 2, 5, 24, 40
+    g = torch.Generator().manual_seed(29)
+    logits = (torch.randn(B, nc, H, W, generator=g) * 2)
+    target = torch.randint(0, nc, (B, H, W), generator=g)
+    bad = target.clone()
+    bad[0, 3, 5], bad[1, 7, 9], bad[1, 0, 0] = 255, -1, nc
+    lg = logits.cuda().requires_grad_(True)
+    loss, acc = mfc.mfc_loss(lg, bad.cuda())
+    loss.backward()
+    assert int(acc[29]) == 3 and bool(torch.isfinite(lg.grad).all()) and bool(torch.isfinite(loss))
+    logp = F.log_softmax(logits, 1)
+    tg = bad.clone()
+    tg[(bad < 0) | (bad >= nc)] = -100
+    nll = F.nll_loss(logp, tg, weight=torch.tensor([1.0, 1000.0, 1000.0, 1000.0, 1000.0]), ignore_index=-100)
+    assert abs(float(acc[26]) - float(nll)) < 1e-5
+    with pytest.raises(IndexError):
+        mfc.mfc_loss(lg.detach(), bad.cuda(), check_labels=True)
+    _, acc_ok = mfc.mfc_loss(lg.detach(), target.cuda(), check_labels=True)
+    assert int(acc_ok[29]) == 0
+
+
 def test_loss_global_batch_split(M):
     """Data-parallel form of the loss: two 'ranks' (two halves of the batch on one GPU) run mfc_loss_partial, their 26 sums
     are added (what dist.allreduce_loss_sums does over RCCL), mfc_loss_finalize / mfc_loss_bwd then use the global sums.

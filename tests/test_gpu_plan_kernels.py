@@ -1,0 +1,159 @@
+"""The launches the BENCHMARKED plan actually makes (BASELINE.json configs[2]: T=3, B=8, 480x640, bf16; HRNet-w32 and -w48): every
+distinct convolution node of that plan -- forward launch, data-gradient launch(es) and weight-gradient launch, with the plan's own
+descriptors (so the geometry the library's search picks for N = 24 images at 120x160 ... 15x20, persistent ranges, XCD remap,
+8-wave forms, split-K slices) -- is run once on seeded tensors and compared with PyTorch's CPU fp32 operators (F.conv2d + autograd)
+applied to the SAME bf16-rounded inputs.  Tolerance 1.5e-2 of the output scale (bf16 output rounding; fp32 accumulation), as in
+tests/test_gpu_ops.py, whose toy shapes need not reach these instantiations.
+Reference operators replaced: models/hrnet.py:58-74 (BasicBlock convs), :95-115, :200-230, :334-351; multiframe_model.py:191-201.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1.5e-2
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def bf(t):
+    return t.bfloat16().float()
+
+
+def _fields(s, skip):
+    return tuple(getattr(s, n) for n, _ in s._fields_[skip:])
+
+
+def node_key(ci):
+    f, g = ci.fwd, ci.wg
+    return (_fields(f, 6) + (bool(f.bias), bool(f.in_coef), bool(f.out_stats)),
+            tuple(_fields(d, 6) for d in ci.dgrad), _fields(g, 4) + (bool(g.in_coef),))
+
+
+def unique_nodes(width, B=8, H=480, W=640, T=3):
+    import mfcnet_amd as mfc
+    from mfcnet_amd.plan import Plan
+    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=T, pretrained=False, width=width, compute_dtype="bf16").train()
+    pl = Plan(m, B, H, W, False, False, True, True, True, torch.device("cpu"), dry=True)
+    seen = {}
+    for op in pl.ops:
+        if op[0] == "conv":
+            seen.setdefault(node_key(op[3]), op[3])
+    return list(seen.values())
+
+
+def clone_desc(d):
+    c = type(d)()
+    C.memmove(C.byref(c), C.byref(d), C.sizeof(d))
+    return c
+
+
+def nhwc(t_nchw, Cp):
+    """CPU fp32 NCHW (already bf16-rounded) -> device bf16 NHWC with zero channel padding"""
+    N, Cc, H, W = t_nchw.shape
+    out = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16)
+    out[..., :Cc] = t_nchw.permute(0, 2, 3, 1).bfloat16()
+    return out.cuda()
+
+
+def nchw(t_nhwc, Cc):
+    return t_nhwc[..., :Cc].permute(0, 3, 1, 2).float().cpu()
+
+
+def run_node(ci, L, ops, seed):
+    f = ci.fwd
+    N, Hin, Win, Cin, Cout, k, s, pad = f.N, f.Hin, f.Win, f.Cin, f.Cout, ci.k, ci.stride, ci.pad
+    G, ipg = f.N // f.images_per_group, f.images_per_group
+    g = torch.Generator().manual_seed(seed)
+    x = bf(torch.randn(N, Cin, Hin, Win, generator=g))
+    w = bf(torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k))
+    bias = torch.randn(Cout, generator=g) if f.bias else None
+    coef = None
+    xa = x
+    if f.in_coef:
+        scale, shift = torch.rand(G, Cin, generator=g) + 0.5, torch.randn(G, Cin, generator=g) * 0.3
+        coef = torch.zeros(G, 4, f.Cin_p)
+        coef[:, 0, :Cin], coef[:, 1, :Cin] = scale, shift
+        xa = x.view(G, ipg, Cin, Hin, Win) * scale.view(G, 1, Cin, 1, 1) + shift.view(G, 1, Cin, 1, 1)
+        xa = bf((F.relu(xa) if f.in_relu else xa).reshape(N, Cin, Hin, Win))      # the kernels round the transformed operand to bf16
+    xa = xa.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(xa, wr, bias, stride=s, padding=pad)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    what = f"{ci.wname} {Cin}->{Cout} k{k} s{s} {Hin}x{Win} N{N}"
+
+    # ---- forward launch, the plan's descriptor with test tensors
+    xd = nhwc(x, f.Cin_p)
+    d = clone_desc(f)
+    out = torch.zeros(N, f.Hout, f.Wout, f.Cout_p, dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(L.STAT_REPLICAS, G, 2, f.Cout_p, device="cuda") if f.out_stats else None
+    coef_d = coef.cuda() if coef is not None else None
+    bias_d = bias.cuda() if bias is not None else None
+    d.inp, d.out = xd.data_ptr(), out.data_ptr()
+    d.bias = bias_d.data_ptr() if bias_d is not None else 0
+    d.in_coef = coef_d.data_ptr() if coef_d is not None else 0
+    d.out_stats = stats.data_ptr() if stats is not None else 0
+    wp = ops.pack_weight(w.cuda(), d, "fwd")
+    d.wp = wp.data_ptr()
+    L.call(L.lib.mfc_conv2d_fwd, d)
+    yo = nchw(out, Cout)
+    assert relerr(yo, y.detach()) < TOL, ("fwd", what, relerr(yo, y.detach()))
+    if f.Cout_p > Cout:
+        assert float(out[..., Cout:].float().abs().max()) == 0.0, ("fwd padding", what)
+    if stats is not None:
+        st = stats.sum(0).cpu()
+        yr = y.detach().view(G, ipg, Cout, f.Hout, f.Wout)
+        assert relerr(st[:, 0, :Cout], yr.sum((1, 3, 4))) < 5 * TOL, ("stats sum", what)
+        assert relerr(st[:, 1, :Cout], (yr * yr).sum((1, 3, 4))) < 5 * TOL, ("stats sumsq", what)
+
+    # ---- data-gradient launch(es): 1 for stride 1, 4 output-parity classes for stride 2
+    dyd = nhwc(dy, f.Cout_p)
+    if ci.dgrad:
+        acc = ci.dgrad[0].accumulate
+        base = bf(torch.randn(N, Cin, Hin, Win, generator=g)) if acc else torch.zeros(N, Cin, Hin, Win)
+        dx = nhwc(base, f.Cin_p)
+        keep = []
+        for dg in ci.dgrad:
+            q = clone_desc(dg)
+            q.inp, q.out, q.bias, q.in_coef, q.out_stats = dyd.data_ptr(), dx.data_ptr(), 0, 0, 0
+            mode, cls = ("dgrad", (0, 0)) if s == 1 else ("dgrad_s2", (q.out_oh, q.out_ow))
+            wq = ops.pack_weight(w.cuda(), q, mode, cls)
+            keep.append(wq)
+            q.wp = wq.data_ptr()
+            L.call(L.lib.mfc_conv2d_fwd, q)
+        torch.cuda.synchronize()
+        ref = xa.grad + base
+        e = relerr(nchw(dx, Cin), ref)
+        assert e < (2 if acc else 1) * TOL, ("dgrad", what, e)
+
+    # ---- weight-gradient launch (+ unpack of its partial-sum slices)
+    wg = clone_desc(ci.wg)
+    parts = L.wgrad_parts(wg)
+    Co16, Ci16 = ops.rup(Cout, 16), ops.rup(Cin, 16)
+    dwp = torch.zeros(parts * k * k * Co16 * Ci16, dtype=torch.float32, device="cuda")
+    wg.x, wg.dy, wg.dwp = xd.data_ptr(), dyd.data_ptr(), dwp.data_ptr()
+    wg.in_coef = coef_d.data_ptr() if coef_d is not None else 0
+    L.call(L.lib.mfc_conv2d_wgrad, wg)
+    dw = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device="cuda")
+    ops._run_jobs([dict(src=dwp.data_ptr(), dst=dw.data_ptr(), Cout=Cout, Cin=Cin, KH=k, KW=k, Co16=Co16, Ci16=Ci16, nparts=parts)],
+                  L.UnpackJob, L.lib.mfc_unpack_wgrad)
+    e = relerr(dw.cpu(), wr.grad)
+    assert e < TOL, ("wgrad", what, e, parts)
+    return what
+
+
+@pytest.mark.parametrize("width", [32, 48])
+def test_every_conv_node_of_the_benchmarked_plan(width):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mfcnet_amd import _lib as L, ops
+    nodes = unique_nodes(width)
+    assert 30 <= len(nodes) <= 60
+    done = [run_node(ci, L, ops, 100 + i) for i, ci in enumerate(nodes)]
+    print(f"w{width}: {len(done)} distinct convolution nodes (fwd + dgrad + wgrad) of the B=8 480x640 bf16 plan match CPU fp32")

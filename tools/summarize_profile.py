@@ -11,9 +11,55 @@ import csv, json, os, re, sqlite3, sys
 from collections import defaultdict
 
 
+_demangled = {}
+
+
+def _demangle(name):
+    """Itanium names of this library's kernel templates (rocprofv3 prints some of them mangled; binutils' c++filt does not know the
+    __bf16 code DF16b): _Z<len><name>I<args>E... with args in {DF16b, f, Li<n>E, Lb<0|1>E}."""
+    m = re.match(r"_Z(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+    if not rest.startswith("I"):
+        return base
+    args, i = [], 1
+    while i < len(rest) and rest[i] != "E":
+        if rest.startswith("DF16b", i):
+            args.append("__bf16"); i += 5
+        elif rest[i] == "f":
+            args.append("float"); i += 1
+        elif rest.startswith("Lb", i):
+            args.append("true" if rest[i + 2] == "1" else "false"); i += 4
+        elif rest.startswith("Li", i):
+            j = rest.index("E", i)
+            v = rest[i + 2:j]
+            args.append("-" + v[1:] if v.startswith("n") else v); i = j + 1
+        else:
+            return name                      # unknown code: leave the name alone
+    return f"{base}<{', '.join(args)}>"
+
+
 def short(name):
-    name = re.sub(r"^void ", "", name)
-    return re.sub(r"\(.*$", "", name)
+    """kernel name as bench.py's profiler rows spell it: demangled, no return type, no argument list"""
+    if name not in _demangled:
+        out = _demangle(name) if name.startswith("_Z") else name
+        out = re.sub(r"^void ", "", out)
+        depth, cut = 0, len(out)
+        for i, ch in enumerate(out):           # cut at the argument list's '(' (outside template brackets)
+            if ch == "<":
+                depth += 1
+            elif ch == ">":
+                depth -= 1
+            elif ch == "(" and depth == 0:
+                cut = i
+                break
+        _demangled[name] = out[:cut].strip()
+    return _demangled[name]
+
+
+SETUP = ("__amd_rocclr_", "at::native::", "pack_weights_kernel")      # model set-up (load_state_dict copies, fills, weight packing): not the step
 
 
 def kernel_stats(db_path):
@@ -21,6 +67,8 @@ def kernel_stats(db_path):
     rows = db.execute("select name, duration from kernels").fetchall()
     agg = defaultdict(list)
     for n, d in rows:
+        if any(short(n).startswith(p) for p in SETUP):
+            continue
         agg[short(n)].append(d)
     tot = sum(sum(v) for v in agg.values())
     out = []
@@ -54,6 +102,25 @@ def main():
         print(mode, "top kernels:")
         for r in st[:8]:
             print(f"  {r['percent']:6.2f}%  n={r['calls']:5d}  avg {r['avg_ns'] / 1e3:8.1f} us  {r['kernel'][:90]}")
+    pm = os.path.join(src, "pmc_mfma", "mfma_results.db")
+    if os.path.exists(pm):
+        # MFMA utilisation (north_star): SQ_VALU_MFMA_BUSY_CYCLES = cycles the matrix pipes were busy, summed over all SIMDs;
+        # GRBM_GUI_ACTIVE = busy clocks summed over the 8 XCDs.  util = MFMA busy / (kernel clocks x 1024 SIMDs).
+        mb, sb, ga = pmc_avg(pm, "SQ_VALU_MFMA_BUSY_CYCLES"), pmc_avg(pm, "SQ_BUSY_CYCLES"), pmc_avg(pm, "GRBM_GUI_ACTIVE")
+        out = {"note": "per-dispatch averages over one serial training step (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE); "
+                       "mfma_util = MFMA busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); mfma_busy_over_sq_busy = the raw counter ratio",
+               "kernels": {}}
+        for n, (v, calls) in mb.items():
+            gui = ga.get(n, (0.0, 0))[0]
+            sq = sb.get(n, (0.0, 0))[0]
+            out["kernels"][n] = {"dispatches": calls, "mfma_busy_cycles": round(v), "sq_busy_cycles": round(sq), "grbm_gui_active": round(gui),
+                                 "mfma_util": round(v / (gui / 8.0 * 1024.0), 4) if gui else None,
+                                 "mfma_busy_over_sq_busy": round(v / sq, 4) if sq else None}
+        with open(os.path.join(root, "profiles", f"{tag}_pmc_mfma.json"), "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+        for n in sorted(out["kernels"], key=lambda k: -out["kernels"][k]["mfma_busy_cycles"] * out["kernels"][k]["dispatches"])[:8]:
+            k = out["kernels"][n]
+            print(f"  mfma {k['dispatches']:5d} x util {k['mfma_util']}  busy/sq_busy {k['mfma_busy_over_sq_busy']}  {n[:90]}")
     pf, pw = os.path.join(src, "pmc_fetch", "fetch_results.db"), os.path.join(src, "pmc_write", "write_results.db")
     if os.path.exists(pf) and os.path.exists(pw):
         fe, wr = pmc_avg(pf, "FETCH_SIZE"), pmc_avg(pw, "WRITE_SIZE")
