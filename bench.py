@@ -64,7 +64,8 @@ def launch_ranks(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MFC_BENCH_LAUNCHER="bench.py")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     for ln in r.stdout.splitlines():
@@ -363,7 +364,7 @@ def main():
                "config": {"workload": f"{'single-frame HRNet' if args.single else 'MFCNet'}{'-Basic' if args.basic else ''} T={T} {'RGB' + extra if extra else 'RGB-only'} (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, {'eval forward only' if args.fwd_only else 'fwd+bwd+Adam'} "
                                       f"({cfg_label})", "width": args.width, "global_batch": world * B,
                           "frames_per_clip": T, "parallelism": f"dp{world}", "ranks": world,
-                          "backend": (args.backend if world > 1 else None), "launcher": "external" if external else "bench.py",
+                          "backend": (args.backend if world > 1 else None), "launcher": os.environ.get("MFC_BENCH_LAUNCHER", "external" if external else "bench.py"),
                           "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
                "roofline": roof, "roofline_conv": roof_conv}
         if world == 1 and not args.no_cpu_baseline:

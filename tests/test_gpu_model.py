@@ -139,14 +139,18 @@ def test_state_dict_roundtrip_and_errors(mfc):
         m([t.cpu() for t in x])
 
 
-BF16_EVAL_TOL = 0.02        # of the logit scale; measured values are printed (bf16 storage rounding itself is NOT in this number)
+BF16_EVAL_TOL = 0.02        # max-abs, of the logit scale (mean-abs: 0.3 %); measured: max 1.0-1.5 %, mean 0.12-0.19 % (printed)
 
 
 def _bf16_vs_storage_oracle(mfc, cfg, width, single=False):
     """HIP bf16 (throughput mode) eval logits against the CPU oracle run with the SAME storage rounding (oracle `store_dtype=bfloat16`:
-    every tensor the plan materialises is rounded to bf16 where the plan rounds it).  What is left between the two is fp32 summation
-    order plus the rare bf16 rounding flips it causes (one flip = 2^-8 of one activation), so the bound is tight: max-abs <= 2 % of the
-    logit scale and mean-abs <= 0.2 %, where bf16 vs the fp32 oracle differs by several per cent."""
+    every tensor the plan materialises is rounded to bf16 where the plan rounds it), so the storage rounding itself is common to both
+    sides and only fp32 summation order differs.  That is NOT a 1e-6 difference at the output: a relative perturbation eps of a tensor
+    flips the bf16 rounding of a fraction eps / 2^-8 of its elements by one ulp each, i.e. it is re-amplified to sqrt(eps * 2^-8) at
+    every rounding point, so two bf16 pipelines drift apart to about one bf16 ulp of the logits within a few layers whatever their
+    arithmetic.  The bound is therefore a few output ulps: max-abs <= 2 % of the logit scale and mean-abs <= 0.3 % (measured 1.0-1.5 %
+    and 0.12-0.19 %, i.e. ~3 and ~0.3 ulp of a value at the scale; a wrong tap, channel or coefficient anywhere moves it by tens of
+    per cent).  Exactness of the bf16 kernels proper is pinned per launch in tests/test_gpu_plan_kernels.py."""
     from oracle import mfcnet_oracle as O
     frames, flows, depths, mask = case_inputs(cfg)
     if single:
@@ -169,7 +173,7 @@ def _bf16_vs_storage_oracle(mfc, cfg, width, single=False):
     scale = float(ref.abs().max())
     mx, mean = float((y - ref).abs().max()), float((y - ref).abs().mean())
     print(f"bf16 vs bf16-storage oracle [{cfg['name']} w{width}]: max {mx:.3e} mean {mean:.3e} of scale {scale:.3e}")
-    assert mx <= BF16_EVAL_TOL * scale and mean <= 0.1 * BF16_EVAL_TOL * scale, (mx, mean, scale)
+    assert mx <= BF16_EVAL_TOL * scale and mean <= 0.15 * BF16_EVAL_TOL * scale, (mx, mean, scale)
     return m, net
 
 
@@ -560,6 +564,9 @@ def test_head_only_training_three_steps_vs_oracle(mfc):
     frames, flows, depths, mask = case_inputs(cfg)
     sd = case_state(cfg)
     net = O.Net(sd, cfg["model_type"], 48, 5, cfg["T"], cfg["optflow"], cfg["depth"]).train(base=False, head=True)
+    for n in net.param_names:                                  # `param.requires_grad = False` for base_model (:161-162)
+        if n.startswith("base_model."):
+            net.sd[n].requires_grad_(False)
     opt_o = torch.optim.Adam(net.params("multiframe_net."), lr=1e-3)
     m = build(mfc, cfg)
     set_mode(m, "headonly")
