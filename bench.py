@@ -133,7 +133,7 @@ def cpu_baseline(width, T, H, W):
     from oracle import mfcnet_oracle as O
     torch.manual_seed(0)
     model, logical, usable = host_cpu()
-    threads = min(usable, 64)                     # B=1 convolutions stop scaling (and oversubscribe) beyond the physical cores
+    threads = min(usable, 32)                     # B=1 convolutions stop scaling beyond ~32 threads (measured on the 64-core EPYC 9575F host: 1.1 frames/s at 32, 0.43 at 64)
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(42)
 

@@ -21,8 +21,6 @@ def main():
     # eval-mode BatchNorm (running statistics): no statistic atomics, so the two orders must agree to fp32 rounding of the all-reduce
     # itself -- a bucket reduced before its gradients were final would be off by O(1)
     model = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, width=16, compute_dtype="fp32").cuda().eval()
-    with torch.no_grad():
-        model._RS.uniform_(0.5, 1.5)          # (running_mean / running_var: any positive values)
     broadcast_params(model)
     g = torch.Generator().manual_seed(100 + rank)
     frames = [torch.randn(2, 3, 64, 96, generator=g).cuda() for _ in range(3)]
