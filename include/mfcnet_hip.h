@@ -90,13 +90,31 @@ typedef struct {
     int32_t out_sh, out_sw, out_oh, out_ow;
     int32_t in_relu, images_per_group, accumulate;
     int32_t TH, TW;                        /* pixel tile (TH*TW <= 128); 0 = choose */
+    /* ---- optional epilogue fusions of a DATA-GRADIENT launch (bf16, launches whose mfc_conv_layout reports fa = 1) ----
+     * acc_src: with `accumulate`, the running sum is read from THIS tensor (same geometry as out) instead of from out itself:
+     *          out = acc + acc_src.  (The residual branch of a BasicBlock, hrnet.py:71: the block input's gradient is the masked block-output
+     *          gradient plus conv1's data gradient -- no copy of the former is made.)
+     * bn_y:    BatchNorm / ReLU backward statistics of the tensor this launch completes (precedent: inplace_abn_cuda.cu:174-256 edz_eydz):
+     *          with v = the final value of an output element, m its mask (bn_mask_mode 0: 1; 2: bn_y*scale+shift > 0; 3: bit of bn_bits, the
+     *          1-bit image mfc_combine_fwd wrote) the launch stores v*m instead of v and adds sum v*m and sum v*m*yhat (yhat = (bn_y - mean) * rstd,
+     *          coefficients from bn_coef [G][4][Cout_p]) to out_stats [MFC_STAT_REPLICAS][G][2][Cout_p] -- i.e. it does the work of
+     *          mfc_bnbwd_reduce (with its masked-gradient output) in the epilogue, and mfc_bnbwd_apply then runs with mask_mode 0. */
+    const void* acc_src;     /* T [N, Hout, Wout, Cout_p] or NULL */
+    const void* bn_y;        /* T [N, Hout, Wout, Cout_p] (pre-BatchNorm conv output) or NULL */
+    const float* bn_coef;    /* [G][4][Cout_p] coefficient block of that BatchNorm */
+    const void* bn_bits;     /* uint8 [N*Hout*Wout*Cout_p/8] (bn_mask_mode 3) */
+    int32_t bn_mask_mode;
+    int32_t flags;           /* bit 0 (MFC_CONV_WANT_FA): restrict the geometry search to launches that support the fusions above (fa = 1) when one
+                              * exists -- set it BEFORE mfc_conv2d_layout / packing, so that the packed weight image matches the launch */
 } mfc_conv_desc;
+#define MFC_CONV_WANT_FA 1
 int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream);
 /* The packed weight image a launch of `d` reads is laid out [TA/TAS][nchunks][Yblocks][nslots][NT16][granule]
  * (slot = (row-in-group, tap column, granule-in-chunk)): the weights of one (tap-row group, channel chunk, cout block) stage are one contiguous block that is DMA-copied
  * straight into LDS.  The blocking depends on the launch geometry, so the packer asks for it here.      */
 typedef struct { int32_t KG, nchunks, NT16, Yblocks, nslots, TA, TB, lds_bytes; int64_t bytes;
-                 int32_t MT, TH, TW, grid, per_block, TAS, NW, pad_; } mfc_conv_layout;   /* last row: launch geometry (informational; NW = waves per workgroup) */
+                 int32_t MT, TH, TW, grid, per_block, TAS, NW, fa; } mfc_conv_layout;   /* last row: launch geometry (informational; NW = waves per workgroup;
+                                                                                          * fa = 1: the launch supports the acc_src / bn_y epilogue fusions) */
 int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
 /* LDS bytes a launch of `d` needs (for tests / planners); <0 on invalid desc. */
 int mfc_conv2d_lds_bytes(const mfc_conv_desc* d);
@@ -406,6 +424,7 @@ int mfc_program_profile(const mfc_op* ops, int32_t n, int32_t reps, float* ms_ou
  * under profiles/.  Only meaningful when every record runs on one stream (mfc_set_flag(9, 0)): with lanes a launch shares the GPU. */
 typedef struct { char name[120]; double ms, flops, bytes; int64_t launches; } mfc_prof_entry;
 int mfc_prof_enable(int on);
+int mfc_prof_dump(const char* csv_path);                     /* tuning aid: the recorded launches as a timeline (name, stream, start_us, end_us); clears the log */
 int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the recorded events, fills out[0..n), clears the log; returns n (< 0: error) */
 
 /* Tuning switches (defaults are the measured optima; the tools/ scripts sweep them).  Process-global, not thread-safe.
@@ -425,7 +444,8 @@ int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the 
  *  24  conv: smallest Cin and Cout sent to that GEMM (128)
  *  25  wgrad: 1x1 weight gradients without input transform as a split-K GEMM (wgrad_gemm1x1.hip) (1)
  *  26  wgrad: smallest Cin and Cout sent to that GEMM (64)           27  BN-backward reduce: workgroups per launch (1024; 512-2048 measured equal)
- *  28  program: defer the final join of the detached stream to the next program (0; set by the segmented backward) */
+ *  28  program: defer the final join of the detached stream to the next program (0; set by the segmented backward)
+ *  29  wgrad: 3x3 / stride-1 weight gradients of 32-channel-multiple layers through the LDS-DMA ring kernel (conv_wgrad_dma.hip) (1) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

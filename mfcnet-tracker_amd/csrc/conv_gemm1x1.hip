@@ -325,7 +325,7 @@ int gemm1x1_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
     out->nslots = G_KG; out->TA = 1; out->TB = 1; out->TAS = 1; out->lds_bytes = G_LDS;
     out->bytes = (int64_t)out->nchunks * out->Yblocks * G_BBYTES;
     const int ntiles = (int)(((long)d->N * d->Hout * d->Wout) / G_BM);
-    out->MT = 8; out->TH = 1; out->TW = G_BM; out->grid = ntiles < 256 ? ntiles : 256; out->per_block = ceil_div(ntiles, out->grid); out->NW = 8; out->pad_ = 0;
+    out->MT = 8; out->TH = 1; out->TW = G_BM; out->grid = ntiles < 256 ? ntiles : 256; out->per_block = ceil_div(ntiles, out->grid); out->NW = 8; out->fa = 0;
     return MFC_OK;
 }
 

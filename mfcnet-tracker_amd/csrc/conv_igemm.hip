@@ -41,6 +41,8 @@ struct ConvK {
     int ybfast;                              // unit order: 1 = cout block fastest (the Yblocks units of a pixel tile run back to back on one workgroup: the re-reads of the tile hit L2 instead of HBM)
     int wres;                                // >0: single-stage launch whose Yblocks weight stages ALL stay in LDS (wres = Yblocks); the pixel tile is staged once for its Yblocks units
     int ablate;                              // tuning only: 1 skip weight DMA, 2 skip patch staging, 4 skip output stores, 8 skip MFMAs
+    // data-gradient epilogue fusions (bf16 FA variants; include/mfcnet_hip.h): accumulate from another tensor; BatchNorm-backward statistics
+    const char* acc_src; const char* bn_y; const float* bn_coef; const unsigned char* bn_bits; int bn_mode;
 };
 
 template <int CTRL> __device__ inline float dpp_add(float v) {
@@ -55,7 +57,9 @@ __device__ inline float row16_sum(float v) {
 // NW = waves per workgroup: 4 (two workgroups per CU, 80 KiB LDS each) or 8 (ONE workgroup per CU with the whole 160 KiB: the
 // weight stage is shared by twice the waves, so the channel chunk doubles and the number of stages -- each with its fixed
 // prefetch-issue / barrier cost -- halves)
-template <typename T, int NT, int MT, int PMAX, int NW>
+// FUSE: the data-gradient epilogue fusions (acc_src / bn_y) are compiled in (FA variants only; a separate instantiation, so that
+// the register allocation of the plain kernels is untouched)
+template <typename T, int NT, int MT, int PMAX, int NW, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(ConvK p) {
     constexpr int E = Gran<T>::E;
     constexpr bool BF = (E == 8);
@@ -269,8 +273,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                 const float sa = row16_sum(ssum[nt][r]), sb = row16_sum(ssq[nt][r]);
                 ssum[nt][r] = 0.f; ssq[nt][r] = 0.f;
                 if ((lane & 15) == 0) {
-                    red[red_par * 2 * NW * NT16 + (wave * 2 + 0) * NT16 + nt * 16 + cq + r] = sa;
-                    red[red_par * 2 * NW * NT16 + (wave * 2 + 1) * NT16 + nt * 16 + cq + r] = sb;
+                    // (BatchNorm-backward mode keeps the sums in the TRANSPOSED pair layout of the epilogue: entry [nt][r] of row g = lane >> 4
+                    //  is channel (nt / 2) * 32 + 8 g + (nt & 1) * 4 + r)
+                    const int cl = (FUSE && p.bn_y) ? ((nt >> 1) * 32 + (lane >> 4) * 8 + (nt & 1) * 4 + r) : (nt * 16 + cq + r);
+                    red[red_par * 2 * NW * NT16 + (wave * 2 + 0) * NT16 + cl] = sa;
+                    red[red_par * 2 * NW * NT16 + (wave * 2 + 1) * NT16 + cl] = sb;
                 }
             }
         red_pending = true; red_n0 = n0; red_grp = grp; red_rep = rep; red_par ^= 1;
@@ -386,7 +393,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                 // are transposed across the four 16-lane rows (v_permlane32_swap + v_permlane16_swap) so that every lane owns
                 // 8 CONTIGUOUS channels of its pixel -> one 16-byte store per tile pair, 64 contiguous bytes per pixel (the
                 // 8-byte stores to 32-byte half lines cost ~250 cycles of issue each: the memory pipeline works per line touched)
-                char* tbase = p.out + ((((size_t)n * p.Hout + (i0 * p.osh + p.ooh)) * p.Wout + (j0 * p.osw + p.oow)) * p.Cout_p + n0) * sizeof(T);
+                const size_t toff = ((((size_t)n * p.Hout + (i0 * p.osh + p.ooh)) * p.Wout + (j0 * p.osw + p.oow)) * p.Cout_p + n0) * sizeof(T);
+                char* tbase = p.out + toff;
+                const char* abase = ((FUSE && p.acc_src) ? p.acc_src : (const char*)p.out) + toff;      // where the running sum of an accumulating launch lives
+                const bool bnm = FUSE && BF && p.bn_y != nullptr;                             // fused BatchNorm-backward statistics (wave-uniform)
                 const bool full = (i0 + p.TH <= p.Hl) && (j0 + p.TW <= p.Wl);
                 constexpr int NP = BF ? NT / 2 : 0;              // cout tile pairs stored transposed
 #pragma unroll
@@ -415,8 +425,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                             const unsigned off = (unsigned)(eoff16[mt] + pr * 64);
                             const bool vc = (n0 + pr * 32 + (lane >> 4) * 8) < p.Cout_p;
                             uint4 oldq = make_uint4(0, 0, 0, 0);
-                            if (p.accumulate) oldq = *(const uint4*)(tbase + ((vpx && vc) ? off : 0u));
-                            if (p.accumulate) {
+                            if (p.accumulate) oldq = *(const uint4*)(abase + ((vpx && vc) ? off : 0u));
+                            if (p.accumulate || bnm) {
                                 // dgrad accumulation happens in fp32 on the transposed layout: expand, transpose, add, round once
                                 float w[8];
                                 // (the sums must be rounded once: transpose the fp32 values as raw dwords)
@@ -431,7 +441,41 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                                 Gran<T>::unpack(oldq, o8);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { w[r] = __uint_as_float(t0[r]) + o8[r]; w[4 + r] = __uint_as_float(t1[r]) + o8[4 + r]; }
-                                if (p.out_stats) {
+                                if (bnm) {
+                                    // BatchNorm / ReLU backward of the tensor this launch completes: mask, store the MASKED gradient, and keep
+                                    // sum g*m, sum g*m*yhat of the lane's 8 channels (what mfc_bnbwd_reduce would sweep the tensor for again)
+                                    const bool live = vpx && vc;
+                                    const unsigned lo = live ? off : 0u;
+                                    float yv[8];
+                                    Gran<T>::unpack(*(const uint4*)(p.bn_y + toff + lo), yv);
+                                    const int ch = min(n0 + pr * 32 + (lane >> 4) * 8, p.Cout_p - 8);
+                                    const float* cf = p.bn_coef + (size_t)(n / p.ipg) * 4 * p.Cout_p + ch;
+                                    const float4 m0 = *(const float4*)(cf + 2 * p.Cout_p), m1 = *(const float4*)(cf + 2 * p.Cout_p + 4);
+                                    const float4 r0 = *(const float4*)(cf + 3 * p.Cout_p), r1 = *(const float4*)(cf + 3 * p.Cout_p + 4);
+                                    const float mean[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                                    const float rstd[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                                    unsigned mk = 0xffu;
+                                    if (p.bn_mode == 2) {
+                                        const float4 s0 = *(const float4*)cf, s1 = *(const float4*)(cf + 4);
+                                        const float4 h0 = *(const float4*)(cf + p.Cout_p), h1 = *(const float4*)(cf + p.Cout_p + 4);
+                                        const float sc8[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                                        const float sh8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                                        mk = 0;
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) mk |= ((yv[e] * sc8[e] + sh8[e]) > 0.f ? 1u : 0u) << e;
+                                    } else if (p.bn_mode == 3) {
+                                        mk = p.bn_bits[(toff + lo) >> 4];          // one byte per 8-channel granule (mfc_combine_fwd)
+                                    }
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) {
+                                        const float gmv = ((mk >> e) & 1u) ? w[e] : 0.f;
+                                        w[e] = gmv;
+                                        if (live) {
+                                            ssum[2 * pr + (e >> 2)][e & 3] += gmv;
+                                            ssq[2 * pr + (e >> 2)][e & 3] += gmv * ((yv[e] - mean[e]) * rstd[e]);
+                                        }
+                                    }
+                                } else if (p.out_stats) {
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
                                         if (vpx && (n0 + 2 * pr * 16 + cq) < p.Cout_p) { ssum[2 * pr][r] += v[2 * pr][r]; ssq[2 * pr][r] += v[2 * pr][r] * v[2 * pr][r]; }
@@ -576,7 +620,11 @@ int mfc_conv_set_grid(int v) { g_conv_grid = v > 0 ? v : 512; return 0; }
 static int g_conv_nw8 = 90;           // 8-wave (one workgroup per CU) geometries: score weight in % (0 = never; 90 sends ties to the 4-wave form); tuning: mfc_set_flag(19, pct)
 int mfc_conv_set_nw8(int v) { g_conv_nw8 = v; return 0; }
 
-static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid, int& NWsel) {
+static bool conv_variant_fa(int dtype, int NT, int MT, int PM, int NW);
+
+static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid, int& NWsel, int pass = 0) {
+    // pass 0 honours MFC_CONV_WANT_FA (fusable geometries only); if none exists the search is repeated unrestricted (pass 1)
+    const bool want_fa = pass == 0 && (d->flags & MFC_CONV_WANT_FA) && d->dtype == MFC_BF16;
     if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
     if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
     const int E = d->dtype == MFC_BF16 ? 8 : 4;
@@ -591,11 +639,13 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     k.Hl = d->Hl; k.Wl = d->Wl; k.TA = d->TA; k.TB = d->TB; k.dh0 = d->dh0; k.dw0 = d->dw0; k.s = d->in_stride;
     k.osh = d->out_sh; k.osw = d->out_sw; k.ooh = d->out_oh; k.oow = d->out_ow;
     k.in_relu = d->in_relu; k.ipg = d->images_per_group; k.G = d->N / d->images_per_group; k.accumulate = d->accumulate;
+    k.acc_src = (const char*)d->acc_src; k.bn_y = (const char*)d->bn_y; k.bn_coef = d->bn_coef; k.bn_bits = (const unsigned char*)d->bn_bits; k.bn_mode = d->bn_mask_mode;
     const int n16 = ceil_div(d->Cout, 16);
     {   // N tile: fewest computed n-tiles, mild preference for wide tiles (more reuse of the staged patch)
         const int cand[5] = {6, 4, 3, 2, 1};
         double bestc = 1e30; NT = 1;
         for (int i = 0; i < 5; ++i) {
+            if (want_fa && n16 % 2 == 0 && cand[i] != 4 && cand[i] != 2) continue;      // the fused epilogue pairs cout tiles: NT in {2, 4}
             double c = (double)ceil_div(n16, cand[i]) * cand[i] * (1.0 + 0.5 / cand[i]);
             if (c < bestc - 1e-9) { bestc = c; NT = cand[i]; }
         }
@@ -656,6 +706,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
                 if (nw == 8) pm_max = mt == 4 ? (NT == 6 ? 0 : 3) : 4;          // (the 8-wave instantiations: <MT 4, PMAX 3> and <MT 2, PMAX 4>)
                 const size_t lds_cap = nw == 8 ? (size_t)156 * 1024 : (size_t)g_conv_lds_kb * 1024;
                 if (l > lds_cap || pm > pm_max || t.nslots > 256) continue;
+                if (want_fa && !conv_variant_fa(d->dtype, NT, mt, pm, nw)) continue;
                 const double mf = (E == 8 ? t.nslots / 4 : t.nslots) * mt * NT;      // MFMAs per wave per stage
                 const double score = eff * fill * ((double)real / t.nslots) * (mf / (mf + 40.0)) * (mt == 4 ? 1.0 : 0.93) * (nw == 8 ? g_conv_nw8 / 100.0 : 1.0);
                 if (score > best_score) { best_score = score; bk = t; bMT = mt; bPM = pm; blds = l; bNW = nw; }
@@ -664,6 +715,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     }
     }
     const bool ok = best_score > 0;
+    if (!ok && want_fa) return conv_setup(d, k, NT, MT, PM, lds, grid, NWsel, 1);
     k = bk; MT = bMT; PM = bPM; lds = blds; NWsel = bNW;
     if (!ok) return MFC_ERR_UNSUPPORTED;
     k.ntiles = k.N * k.tilesY * k.tilesX;
@@ -692,21 +744,34 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     return MFC_OK;
 }
 
-template <typename T, int NT, int MT, int PMAX, int NW>
+// The instantiation conv_dispatch picks for a geometry: its template PMAX (0 = none) and whether it is an FA variant (the epilogue
+// with the transposed 8-channel layout, the only one that implements acc_src / bn_y; even NT so that every cout tile has a partner).
+static bool conv_variant_fa(int dtype, int NT, int MT, int PM, int NW) {
+    int PMAXt = 0;
+    if (dtype == MFC_BF16 && NW == 8) PMAXt = (NT != 6 && MT == 4 && PM <= 3) ? 3 : ((MT == 2 && PM <= 4) ? 4 : 0);
+    else if (NT == 6) PMAXt = (MT == 2 && PM <= 4) ? 4 : 0;
+    else if (MT == 4) PMAXt = PM <= 3 ? 3 : ((NT <= 3 && PM <= 6) ? 6 : 0);
+    else PMAXt = PM <= 4 ? 4 : 10;
+    if (!PMAXt || dtype != MFC_BF16 || (NT != 2 && NT != 4)) return false;
+    if (NT == 4 && MT == 2 && PMAXt == 10) return false;          // (<4,2,10,4> with the fusions compiled in spills: not offered)
+    return (NT * MT <= 8) || (MT == 2 && NT <= 4 && PMAXt <= 4);
+}
+
+template <typename T, int NT, int MT, int PMAX, int NW, bool FUSE = false>
 static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT, MT, PMAX, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT, MT, PMAX, NW, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on) {
-        MFC_PROF_NAME(pname, "conv_igemm_kernel<%s, %d, %d, %d, %d>", mfc_tname<T>(), NT, MT, PMAX, NW);
+        MFC_PROF_NAME(pname, "conv_igemm_kernel<%s, %d, %d, %d, %d, %s>", mfc_tname<T>(), NT, MT, PMAX, NW, FUSE ? "true" : "false");
         const double E = sizeof(T) == 2 ? 8.0 : 4.0;
         const double flops = 2.0 * k.N * k.Hl * k.Wl * (double)k.Cout * k.TA * k.TB * (k.Cin_g * E);
         const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_g * 16.0) / (k.osh * k.osw) + (double)k.N * k.Hl * k.Wl * k.Cout_p * sizeof(T);
         mfc_prof_before(st, pname, flops, bytes);
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT, PMAX, NW>), dim3(grid), dim3(NW * 64), lds, st, k);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT, PMAX, NW, FUSE>), dim3(grid), dim3(NW * 64), lds, st, k);
     if (g_mfc_prof_on) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -730,6 +795,7 @@ extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
     out->TA = k.TA; out->TB = k.TB; out->lds_bytes = (int32_t)lds; out->TAS = k.TAS;
     out->bytes = (int64_t)k.nstg * k.nchunks * k.Yblocks * k.stage_bytes;
     out->MT = MT; out->TH = k.TH; out->TW = k.TW; out->grid = grid; out->per_block = k.per_block; out->NW = NW;
+    out->fa = conv_variant_fa(d->dtype, NT, MT, PM, NW) ? 1 : 0;
     return MFC_OK;
 }
 
@@ -738,6 +804,29 @@ extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
     return rc < 0 ? rc : (int)lds;
+}
+
+// FA instantiations with the epilogue fusions compiled in (bf16, even NT): exactly the set conv_variant_fa() accepts
+template <int NT>
+static int conv_dispatch_fused(const ConvK& k, int MT, int PM, int NW, size_t lds, int grid, hipStream_t st) {
+    typedef bf16_t T;
+    if constexpr (NT == 2 || NT == 4) {
+        if (NW == 8) {
+            if constexpr (NT == 2) { if (MT == 4 && PM <= 3) return conv_launch<T, NT, 4, 3, 8, true>(k, lds, grid, st); }
+            if (MT == 2 && PM <= 4) return conv_launch<T, NT, 2, 4, 8, true>(k, lds, grid, st);
+            return MFC_ERR_UNSUPPORTED;
+        }
+        if (MT == 4) {
+            if constexpr (NT == 2) {
+                if (PM <= 3) return conv_launch<T, NT, 4, 3, 4, true>(k, lds, grid, st);
+                if (PM <= 6) return conv_launch<T, NT, 4, 6, 4, true>(k, lds, grid, st);
+            }
+            return MFC_ERR_UNSUPPORTED;
+        }
+        if (PM <= 4) return conv_launch<T, NT, 2, 4, 4, true>(k, lds, grid, st);
+        if constexpr (NT == 2) return conv_launch<T, NT, 2, 10, 4, true>(k, lds, grid, st);
+    }
+    return MFC_ERR_UNSUPPORTED;
 }
 
 template <typename T, int NT>
@@ -769,10 +858,21 @@ static int conv_dispatch(const ConvK& k, int MT, int PM, int NW, size_t lds, int
 }
 
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
-    if (d && gemm1x1_eligible(d)) return gemm1x1_launch(d, (hipStream_t)stream);
+    const bool fused = d && (d->acc_src || d->bn_y);
+    if (d && gemm1x1_eligible(d)) return fused ? MFC_ERR_UNSUPPORTED : gemm1x1_launch(d, (hipStream_t)stream);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
     if (rc < 0) return rc;
+    if (fused) {      // epilogue fusions: only where mfc_conv2d_layout reported fa = 1; never silently dropped
+        if (!conv_variant_fa(d->dtype, NT, MT, PM, NW)) return MFC_ERR_UNSUPPORTED;
+        if (d->acc_src && !d->accumulate) return MFC_ERR_INVALID_ARG;
+        if (d->bn_y && (!d->bn_coef || !d->out_stats || (d->bn_mask_mode != 0 && d->bn_mask_mode != 2 && d->bn_mask_mode != 3) ||
+                        (d->bn_mask_mode == 3 && !d->bn_bits) || d->bias)) return MFC_ERR_INVALID_ARG;
+        hipStream_t stf = (hipStream_t)stream;
+        if (NT == 2) return conv_dispatch_fused<2>(k, MT, PM, NW, lds, grid, stf);
+        if (NT == 4) return conv_dispatch_fused<4>(k, MT, PM, NW, lds, grid, stf);
+        return MFC_ERR_UNSUPPORTED;
+    }
     hipStream_t st = (hipStream_t)stream;
 #define MFC_CONV_CASE(nt) \
     case nt: return d->dtype == MFC_BF16 ? conv_dispatch<bf16_t, nt>(k, MT, PM, NW, lds, grid, st) : conv_dispatch<float, nt>(k, MT, PM, NW, lds, grid, st);

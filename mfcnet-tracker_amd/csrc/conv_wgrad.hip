@@ -24,7 +24,7 @@ static int g_wgrad_deep = 0;          // prefetch-distance-2 wave kernel when a 
                                      // (35.7 -> 30.2 us), but its 308 VGPRs cannot share a SIMD with a conv wave (246), so next to the
                                      // critical chain the step gets SLOWER (546 -> 530 frames/s): off by default; mfc_set_flag(17, v)
 static int g_wgrad_maxpx = 6000;     // output pixels one workgroup may walk before the pixel axis is split beyond g_wgrad_blocks (0 = never); mfc_set_flag(21, n)
-static int g_wgrad_blocks = 128;     // target workgroups per wave-kernel launch (S = blocks / Y).  Alone, 512 (2 per CU) is fastest; in the
+int g_wgrad_blocks = 128;            // target workgroups per wave-kernel launch (S = blocks / Y).  Alone, 512 (2 per CU) is fastest; in the
                                      // step the launches run on the detached stream next to the critical chain: fewer, longer-lived
                                      // workgroups leave that chain more of every CU AND write fewer partial-sum slices (each launch
                                      // writes blocks x its packed image, which the unpack reads back: 4.7 GB per step at 256).
@@ -43,7 +43,7 @@ int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
-extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks;
+extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma;
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
     if (id == 2) return mfc_conv_set_force_mt(value);
@@ -72,6 +72,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 26) { g_wgrad_gemm_minc = value; return 0; }
     if (id == 27) { g_bnred_blocks = value > 0 ? value : 1024; return 0; }
     if (id == 28) return mfc_set_defer_join(value);
+    if (id == 29) { g_wgrad_dma = value; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 128; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
@@ -1066,6 +1067,10 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only, 
     return MFC_ERR_UNSUPPORTED;
 }
 
+// conv_wgrad_dma.hip
+bool wgrad_dma_eligible(const mfc_wgrad_desc* d);
+int wgrad_dma_parts(const mfc_wgrad_desc* d);
+int wgrad_dma_launch(const mfc_wgrad_desc* d, hipStream_t st);
 // wgrad_gemm1x1.hip
 bool wgrad_gemm1x1_eligible(const mfc_wgrad_desc* d);
 int wgrad_gemm1x1_parts(const mfc_wgrad_desc* d);
@@ -1079,6 +1084,10 @@ static int wgrad_any(const mfc_wgrad_desc* d, void* stream, int* parts_only) {
     if (wgrad_gemm1x1_eligible(d)) {
         if (parts_only) { *parts_only = wgrad_gemm1x1_parts(d); return MFC_OK; }
         return wgrad_gemm1x1_launch(d, (hipStream_t)stream);
+    }
+    if (wgrad_dma_eligible(d)) {
+        if (parts_only) { *parts_only = wgrad_dma_parts(d); return MFC_OK; }
+        return wgrad_dma_launch(d, (hipStream_t)stream);
     }
     {
         int rcf = wgrad_wave(d, (hipStream_t)stream, parts_only);

@@ -226,7 +226,7 @@ extern "C" int mfc_adam_step(float* p, const float* g, float* m, float* v, int64
 #include <string.h>
 int g_mfc_prof_on = 0;
 namespace {
-struct ProfRec { hipEvent_t a, b; const char* name; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; const char* name; double flops, bytes; hipStream_t st; };
 std::vector<ProfRec> g_log;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
@@ -235,12 +235,35 @@ hipEvent_t get_event() {
 }
 }
 void mfc_prof_before(hipStream_t st, const char* name, double flops, double bytes) {
-    ProfRec r; r.a = get_event(); r.b = get_event(); r.name = name; r.flops = flops; r.bytes = bytes;
+    ProfRec r; r.a = get_event(); r.b = get_event(); r.name = name; r.flops = flops; r.bytes = bytes; r.st = st;
     (void)hipEventRecord(r.a, st);
     g_log.push_back(r);
 }
 void mfc_prof_after(hipStream_t st) { (void)hipEventRecord(g_log.back().b, st); }
 extern "C" int mfc_prof_enable(int on) { g_mfc_prof_on = on; return MFC_OK; }
+// Tuning aid: the recorded launches as a timeline (CSV: name, stream, start_us, end_us relative to the first recorded launch; event
+// timestamps are device-wide, so launches on different streams are comparable).  Clears the log like mfc_prof_collect.
+extern "C" int mfc_prof_dump(const char* path) {
+    if (!path) return MFC_ERR_INVALID_ARG;
+    FILE* f = fopen(path, "w");
+    if (!f) return MFC_ERR_INVALID_ARG;
+    fprintf(f, "name,stream,start_us,end_us\n");
+    std::vector<hipStream_t> streams;
+    for (auto& r : g_log) {
+        if (hipEventSynchronize(r.b) != hipSuccess) { fclose(f); return MFC_ERR_LAUNCH; }
+        float t0 = 0.f, t1 = 0.f;
+        (void)hipEventElapsedTime(&t0, g_log.front().a, r.a);
+        (void)hipEventElapsedTime(&t1, g_log.front().a, r.b);
+        int si = -1;
+        for (size_t i = 0; i < streams.size() && si < 0; ++i) if (streams[i] == r.st) si = (int)i;
+        if (si < 0) { si = (int)streams.size(); streams.push_back(r.st); }
+        fprintf(f, "\"%s\",%d,%.2f,%.2f\n", r.name, si, t0 * 1e3, t1 * 1e3);
+    }
+    fclose(f);
+    for (auto& r : g_log) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_log.clear();
+    return MFC_OK;
+}
 extern "C" int mfc_prof_collect(mfc_prof_entry* out, int32_t cap) {
     if (!out || cap <= 0) return MFC_ERR_INVALID_ARG;
     int n = 0;

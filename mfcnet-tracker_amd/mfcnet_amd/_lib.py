@@ -26,6 +26,7 @@ OP_HEAD_FWD, OP_HEAD_BWD, OP_BIAS_GRAD, OP_MEMSET, OP_PACK, OP_UNPACK, OP_NCHW2N
 OP_WGRAD_BATCH = 17
 OP_BNFIN_BATCH = 18
 WGRAD_MAXBATCH = 8
+CONV_WANT_FA = 1
 
 i32, u64, f32, vp = C.c_int32, C.c_uint64, C.c_float, C.c_void_p
 
@@ -36,7 +37,8 @@ class ConvDesc(C.Structure):
                 ("Hout", i32), ("Wout", i32), ("Cout_p", i32), ("Cout", i32), ("Hl", i32), ("Wl", i32),
                 ("TA", i32), ("TB", i32), ("dh0", i32), ("dw0", i32), ("in_stride", i32),
                 ("out_sh", i32), ("out_sw", i32), ("out_oh", i32), ("out_ow", i32),
-                ("in_relu", i32), ("images_per_group", i32), ("accumulate", i32), ("TH", i32), ("TW", i32)]
+                ("in_relu", i32), ("images_per_group", i32), ("accumulate", i32), ("TH", i32), ("TW", i32),
+                ("acc_src", vp), ("bn_y", vp), ("bn_coef", vp), ("bn_bits", vp), ("bn_mask_mode", i32), ("flags", i32)]
 
 
 class PackJob(C.Structure):
@@ -49,7 +51,7 @@ class PackJob(C.Structure):
 class ConvLayout(C.Structure):
     _fields_ = [("KG", i32), ("nchunks", i32), ("NT16", i32), ("Yblocks", i32), ("nslots", i32), ("TA", i32), ("TB", i32),
                 ("lds_bytes", i32), ("bytes", C.c_int64), ("MT", i32), ("TH", i32), ("TW", i32), ("grid", i32),
-                ("per_block", i32), ("TAS", i32), ("NW", i32), ("pad_", i32)]
+                ("per_block", i32), ("TAS", i32), ("NW", i32), ("fa", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -134,7 +136,7 @@ EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_p
            "mfc_bn_finalize", "mfc_bn_finalize_batch", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd", "mfc_confusion_counts", "mfc_adam_step", "mfc_program_run", "mfc_wait_detached", "mfc_program_profile", "mfc_graph_capture", "mfc_graph_launch", "mfc_graph_destroy",
-           "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect"]
+           "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect", "mfc_prof_dump"]
 
 
 class MfcError(RuntimeError):
@@ -179,6 +181,7 @@ def _load():
     lib.mfc_set_flag.argtypes = [i32, i32]
     lib.mfc_prof_enable.argtypes = [i32]
     lib.mfc_prof_collect.argtypes = [vp, i32]
+    lib.mfc_prof_dump.argtypes = [C.c_char_p]
     if lib.mfc_op_size() != C.sizeof(Op):
         raise MfcError(f"mfc_op size mismatch: library {lib.mfc_op_size()} vs python mirror {C.sizeof(Op)}")
     return lib

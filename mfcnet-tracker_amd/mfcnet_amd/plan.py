@@ -62,6 +62,8 @@ class Ten:
     grad: Optional["Ten"] = None
     grad_init: bool = False
     bits: int = 0                 # 1-bit image of (tensor > 0), written by the ReLU'd combine that produced it (bf16 training)
+    last_dgrad: Optional[list] = None     # backward emission: descriptors of the data-gradient launch(es) that wrote this tensor's gradient LAST
+    grad_src: Optional["Ten"] = None      # backward emission: the gradient of this tensor starts from that tensor's gradient (not yet copied)
 
 
 @dataclass
@@ -161,6 +163,9 @@ class Plan:
         self.fuse_fin = getattr(model, "fuse_bn_finalize", True)     # BN-backward finalize inside the apply launch (C <= 128)
         self.mask_bits = getattr(model, "relu_mask_bits", True)     # 1-bit ReLU masks for the BatchNorm backward (bf16)
         self.lanes = getattr(model, "parallel_branches", True)      # branch-parallel lanes of the program (include/mfcnet_hip.h, mfc_op.lane)
+        # BatchNorm-backward reduce passes folded into the epilogue of the data-gradient launch that completes the gradient (bf16):
+        # mfc_conv_desc.bn_y / acc_src (include/mfcnet_hip.h)
+        self.fuse_bnred = bool(getattr(model, "fuse_bnbwd_reduce", True)) and self.dtype == L.BF16 and need_backward
         self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc")}
         self.dry = dry
         self._build()                       # sizing pass
@@ -242,6 +247,7 @@ class Plan:
                 if stride == 1:
                     d = L.ConvDesc(16, 0, 16, 0, 0, 0, self.dtype, y.N, y.H, y.W, y.Cp, cout, xt.H, xt.W, xt.Cp, xt.C, xt.H, xt.W,
                                    k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, y.ipg, 0, 0, 0)
+                    d.flags = L.CONV_WANT_FA if self.fuse_bnred else 0      # (before packing: the weight image follows the geometry)
                     self._pack(d, src, cout, cin, k, TA=k, TB=k, kh0=k - 1, kh_step=-1, kw0=k - 1, kw_step=-1, mode=1)
                     ci.dgrad.append(d)
                 else:
@@ -255,6 +261,7 @@ class Plan:
                                 continue
                             d = L.ConvDesc(16, 0, 16, 0, 0, 0, self.dtype, y.N, y.H, y.W, y.Cp, cout, xt.H, xt.W, xt.Cp, xt.C, Hl, Wl,
                                            ta, tb, dh0, dw0, 1, 2, 2, ph, pw, 0, y.ipg, 0, 0, 0)
+                            d.flags = L.CONV_WANT_FA if self.fuse_bnred else 0
                             self._pack(d, src, cout, cin, k, TA=ta, TB=tb, kh0=kh0, kh_step=-2, kw0=kw0, kw_step=-2, mode=1)
                             ci.dgrad.append(d)
             Co16, Ci16 = rup(cout, 16), rup(cin, 16)
@@ -531,10 +538,12 @@ class Plan:
         return self.conv(o, p + "last_layer.3.weight", self.nc, 1, 1, True).t
 
     # ------------------------------------------------------------------ backward program
-    def _bn_backward(self, bn: BN, y: Ten, g_view: L.View, mask_mode, mask_view, dy_view: L.View, C, gm_view=None, gm_acc=0):
+    def _bn_backward(self, bn: BN, y: Ten, g_view: L.View, mask_mode, mask_view, dy_view: L.View, C, gm_view=None, gm_acc=0,
+                     reduce_fused=False):
         """reduce -> finalize -> apply.  With gm_view the reduce pass also writes the masked gradient g*m there (the
         identity branch of the same sum, += if gm_acc); when it was a plain write, the apply pass reads g*m back from it
-        instead of g and the mask (one tensor less)."""
+        instead of g and the mask (one tensor less).  reduce_fused: the data-gradient launch that completed g has already masked it
+        and accumulated the statistics (mfc_conv_desc.bn_y): no reduce record, g is read with mask_mode 0."""
         def desc(g, mode, mask, dy, acc):
             d = L.BnBwdDesc()
             d.g, d.y = g, self.view(y, bn)
@@ -545,7 +554,8 @@ class Plan:
             d.bstats, d.bcoef = bn.bstats, bn.bcoef
             d.mask_mode, d.dtype, d.N, d.C, d.images_per_group, d.accumulate = mode, self.dtype, y.N, C, y.ipg, acc
             return d
-        self.bwd.append((L.OP_BNBWD_REDUCE, desc(g_view, mask_mode, mask_view, gm_view, gm_acc)))
+        if not reduce_fused:
+            self.bwd.append((L.OP_BNBWD_REDUCE, desc(g_view, mask_mode, mask_view, gm_view, gm_acc)))
         fused_fin = self.fuse_fin and C <= 128 and bn.C <= C and bn.G <= 8
         if not fused_fin:
             self.bwd.append((L.OP_BNBWD_FIN, L.BnBwdFinDesc(bn.bstats, bn.bcoef, self.gptr(bn.name + ".weight"),
@@ -561,6 +571,25 @@ class Plan:
         self.bwd.append((L.OP_BNBWD_APPLY, ad))
         self._grad_ready(bn.name + ".weight")
         self._grad_ready(bn.name + ".bias")
+
+    def _fusable(self, descs) -> bool:
+        """the data-gradient launches `descs` (those that wrote a gradient tensor last) can take the epilogue fusions"""
+        return bool(descs) and self.fuse_bnred and all(L.conv_layout(d).fa == 1 for d in descs)
+
+    def _materialise_grad_src(self, t: Ten):
+        """a pending "the gradient of t starts from the gradient of another tensor" that no data-gradient launch can read in place:
+        make the copy (what the BatchNorm-backward reduce pass used to write)"""
+        src = t.grad_src
+        if src is None:
+            return
+        t.grad_src = None
+        sg = self.grad_of(t)
+        md = L.MaskAddDesc()
+        md.g = L.View(src.ptr, 0, src.H, src.W, src.Cp, 0)
+        md.dst = L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, 0)
+        md.mask_mode, md.dtype, md.N, md.C, md.accumulate = 0, self.dtype, sg.N, rup(t.C, self.E), 1 if t.grad_init else 0
+        self.bwd.append((L.OP_MASK_ADD, md))
+        t.grad_init, t.last_dgrad = True, None
 
     def _emit_backward(self):
         E, Cs = self.E, None
@@ -599,7 +628,15 @@ class Plan:
                     g = self.grad_of(y)
                     assert y.grad_init, y.name
                     gv = L.View(g.ptr, 0, g.H, g.W, g.Cp, 0)
-                    self._bn_backward(bn, y, gv, 2 if getattr(y, "virtual_relu", False) else 0, None, gv, rup(y.C, E))
+                    mmode = 2 if getattr(y, "virtual_relu", False) else 0
+                    if self._fusable(y.last_dgrad):
+                        # the launch(es) that completed d(relu(bn(y))) mask it and accumulate the statistics in their epilogue
+                        for d in y.last_dgrad:
+                            d.bn_y, d.bn_coef, d.out_stats, d.bn_mask_mode, d.bn_bits = y.ptr, bn.coef, bn.bstats, mmode, 0
+                        self._bn_backward(bn, y, gv, 0, None, gv, rup(y.C, E), reduce_fused=True)
+                    else:
+                        self._bn_backward(bn, y, gv, mmode, None, gv, rup(y.C, E))
+                    y.last_dgrad = None
             elif kind == "combine":
                 _, terms, out, out_c_off, Cs, relu = op
                 g = self.grad_of(out)
@@ -610,6 +647,9 @@ class Plan:
                 # (same-resolution BatchNorm terms read the 1-bit image of the mask when the forward wrote one)
                 bmode, bmv = (3, L.View(out.bits, 0, out.H, out.W, out.Cp, out_c_off)) if (relu and out.bits) else (mode, mv)
                 same = lambda tm: tm.t.H == out.H and tm.t.W == out.W
+                for tm in terms:                    # (a term whose gradient is still "borrowed" gets its own copy before anything adds to it)
+                    if tm.t.needs_grad and tm.t.grad_src is not None:
+                        self._materialise_grad_src(tm.t)
                 # The identity term of a ReLU'd sum receives exactly g*m.  If its gradient buffer is still unwritten, let the
                 # BN-backward reduce pass of a same-resolution BN term write it (no separate mask pass), and let every other
                 # term read g*m back from there instead of g and the mask.
@@ -639,7 +679,7 @@ class Plan:
                         if not same(tm):        # adjoint of an up-sampling: separable two-pass form, fp32 workspace [N, H, w, C]
                             md.scratch = self._alloc("act", out.N * out.H * s.W * Cs * 4)
                         self.bwd.append((L.OP_MASK_ADD, md))
-                        s.grad_init = True
+                        s.grad_init, s.last_dgrad = True, None
                         if tm is idt:
                             gmv = L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
                         if tm.bn is not None:       # up-sampled BN term: BN backward at the low resolution, in place
@@ -648,14 +688,25 @@ class Plan:
                     else:
                         assert not s.grad_init, s.name
                         dyv = L.View(sg.ptr, 0, sg.H, sg.W, sg.Cp, tm.c_off)
-                        if tm is fuse_bn:
+                        if tm is fuse_bn and bmode == 3 and len(terms) == 2 and out_c_off == 0 and tm.c_off == 0 and idt.c_off == 0 \
+                                and Cs == rup(out.C, E) == rup(idt.t.C, E) and self._fusable(out.last_dgrad):
+                            # residual block tail (hrnet.py:71-72): the data-gradient launch that completed d(out) has masked it in place
+                            # and holds the statistics; the identity branch's gradient STARTS from that tensor (read in place by the
+                            # first launch that adds to it: mfc_conv_desc.acc_src) -- no reduce pass, no copy
+                            for d in out.last_dgrad:
+                                d.bn_y, d.bn_coef, d.out_stats, d.bn_mask_mode, d.bn_bits = s.ptr, tm.bn.coef, tm.bn.bstats, 3, out.bits
+                            self._bn_backward(tm.bn, s, gv, 0, None, dyv, Cs, reduce_fused=True)
+                            idt.t.grad_src = g
+                            gmv = gv
+                        elif tm is fuse_bn:
                             ig = self.grad_of(idt.t)
                             gmv = L.View(ig.ptr, 0, ig.H, ig.W, ig.Cp, idt.c_off)
                             self._bn_backward(tm.bn, s, gv, bmode, bmv, dyv, Cs, gm_view=gmv, gm_acc=0)
                             idt.t.grad_init = True
+                            idt.t.last_dgrad = None
                         else:
                             self._bn_backward(tm.bn, s, g_in, md_in, m_in, dyv, Cs)
-                        s.grad_init = True
+                        s.grad_init, s.last_dgrad = True, None
             elif kind == "conv":
                 _, x, y, ci, bn = op
                 dy = self.grad_of(y)
@@ -671,11 +722,20 @@ class Plan:
                     self._grad_ready(ci.bias)
                 if xt.needs_grad:
                     dx = self.grad_of(xt)
-                    acc = 1 if xt.grad_init else 0
+                    src = None
+                    if xt.grad_src is not None:
+                        # the gradient of xt starts from another tensor's (the masked output gradient of a residual block): the first
+                        # data-gradient launch reads it in place; any other kind of launch needs a copy first
+                        if not xt.grad_init and self._fusable(ci.dgrad):
+                            src, xt.grad_src = xt.grad_src, None
+                        else:
+                            self._materialise_grad_src(xt)
+                    acc = 1 if (xt.grad_init or src is not None) else 0
                     for d in ci.dgrad:
                         d.inp, d.out, d.accumulate = dy.ptr, dx.ptr, acc
+                        d.acc_src = src.ptr if src is not None else 0
                         self.bwd.append((L.OP_CONV, d))
-                    xt.grad_init = True
+                    xt.grad_init, xt.last_dgrad = True, list(ci.dgrad)
                     if x.bn is not None:
                         xt.virtual_consumed, xt.virtual_relu = True, x.relu
 

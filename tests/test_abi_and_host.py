@@ -113,7 +113,13 @@ def test_plan_builds_without_gpu():
     assert kinds.count(L.OP_CONV) == 311 and kinds.count(L.OP_BNFIN) == 309        # 307 + 4 convs
     bk = [o.kind for o in p.bwd_prog]
     assert bk.count(L.OP_WGRAD) == 311 and bk[-1] == L.OP_UNPACK
-    assert bk.count(L.OP_BNBWD_REDUCE) == bk.count(L.OP_BNBWD_APPLY) == 309
+    # every BatchNorm has an apply record; its reduce is either a record of its own or folded into the data-gradient launch that
+    # completes the gradient it reduces (mfc_conv_desc.bn_y)
+    fused = sum(1 for o in p.bwd_prog if o.kind == L.OP_CONV and o.u.conv.bn_y)
+    assert bk.count(L.OP_BNBWD_APPLY) == 309 and 0 < bk.count(L.OP_BNBWD_REDUCE) < 309 and fused >= 309 - bk.count(L.OP_BNBWD_REDUCE)
+    m.fuse_bnbwd_reduce = False
+    p0 = Plan(m, 2, 64, 96, True, True, True, True, True, torch.device("cpu"), dry=True)
+    assert sum(1 for r in p0.bwd if r[0] == L.OP_BNBWD_REDUCE) == 309
 
 
 def test_gradient_buckets_partition_the_backward_program():

@@ -607,3 +607,40 @@ def test_head_only_training_three_steps_vs_oracle(mfc):
     loss.backward()
     fa.step()
     assert torch.equal(m._P[:m._n_base], base_before)
+
+
+def test_fused_bn_backward_reduce_gives_the_same_gradients(mfc):
+    """bf16 training: the BatchNorm-backward reduce passes are folded into the epilogue of the data-gradient launch that completes
+    their input gradient (mfc_conv_desc.bn_y / acc_src; plan.py `fuse_bnbwd_reduce`).  Same logits, same loss and the same gradients as
+    with the separate reduce records (up to the statistic atomics' order), with ~230 records fewer in the W32 backward program."""
+    from mfcnet_amd import _lib as L
+    cfg = dict(name="fusedbn", model_type="HRNetMulti-Large", T=3, optflow=False, depth=False, B=2, H=96, W=128, mode="train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    res = []
+    for fuse in (True, False):
+        m = build(mfc, cfg, dtype="bf16", width=32)
+        m.fuse_bnbwd_reduce = fuse
+        m.train()
+        y = m(dev(frames))
+        loss, _ = mfc.mfc_loss(y, mask.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        prog = next(iter(m._plans.values())).bwd_prog
+        nred = sum(1 for op in prog if op.kind == L.OP_BNBWD_REDUCE)
+        nfused = sum(1 for op in prog if op.kind == L.OP_CONV and op.u.conv.bn_y)
+        assert (nfused > 150 and nred < 120) if fuse else (nfused == 0 and nred == 309)
+        res.append((y.detach().cpu(), float(loss), m._G.detach().cpu().clone()))
+    (y0, l0, g0), (y1, l1, g1) = res
+    assert torch.equal(y0, y1) or float((y0 - y1).abs().max()) < 0.02 * float(y1.abs().max())
+    assert abs(l0 - l1) < 2e-3
+    assert rel_l2(g0.numpy(), g1.numpy()) < GRAD_RTOL
+    # per-parameter, on the layers whose backward changed most (a wrong channel mapping of the fused sums would show here, not in the norm)
+    m_off = g1
+    named_off = {}
+    off = 0
+    for key in ("base_model.stage2.0.branches.0.1.bn1.weight", "base_model.stage2.0.branches.0.1.bn2.weight",
+                "base_model.stage3.1.branches.2.2.bn2.bias", "base_model.layer1.1.bn2.weight", "base_model.stage2.0.branches.1.0.conv1.weight"):
+        o = m._poff[key]
+        n = dict(m.named_parameters())[key].numel()
+        a, b = g0[o:o + n].double(), g1[o:o + n].double()
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 2 * GRAD_RTOL, key

@@ -143,6 +143,88 @@ def test_conv_dgrad(M, case, dtype):
     assert relerr(ops.to_nchw(dx2, Cin).cpu(), 2 * x.grad) < 2 * TOL[dtype]
 
 
+FUSED_DG_CASES = [  # N, G, Cin, Cout, k, s, H, W, mask mode, accumulate from another tensor
+    (6, 3, 32, 32, 3, 1, 24, 40, 2, False), (6, 3, 32, 32, 3, 1, 24, 40, 3, True), (4, 2, 64, 64, 3, 1, 17, 21, 3, True),
+    (4, 2, 64, 64, 3, 1, 17, 21, 0, False), (6, 3, 64, 128, 3, 2, 30, 40, 2, False), (3, 3, 128, 128, 3, 1, 15, 20, 3, True),
+    (6, 3, 64, 32, 1, 1, 20, 28, 2, False), (3, 1, 32, 64, 3, 2, 23, 30, 2, True)]
+
+
+@pytest.mark.parametrize("case", FUSED_DG_CASES)
+def test_dgrad_fused_bn_backward_reduce(M, case):
+    """mfc_conv_desc.bn_y / acc_src: a data-gradient launch that masks its result, accumulates the BatchNorm-backward statistics
+    (sum g*m, sum g*m*yhat per group and channel) in its epilogue and reads its running sum from another tensor -- against autograd's
+    data gradient with the mask / the sums applied on the CPU (the work mfc_bnbwd_reduce otherwise does in a second sweep)."""
+    _, L, ops = M
+    N, G, Cin, Cout, k, s, H, W, mode, acc = case
+    ipg = N // G
+    x = rnd(torch.bfloat16, N, Cin, H, W, seed=51).requires_grad_(True)
+    w = rnd(torch.bfloat16, Cout, Cin, k, k, seed=52, scale=1.0 / np.sqrt(Cin * k * k))
+    yo = F.conv2d(x, w, None, stride=s, padding=k // 2)
+    dy = rnd(torch.bfloat16, *yo.shape, seed=53)
+    yo.backward(dy)
+    base = rnd(torch.bfloat16, N, Cin, H, W, seed=54) if acc else torch.zeros(N, Cin, H, W)
+    g_ref = x.grad + base                                      # the completed gradient
+    ybn = rnd(torch.bfloat16, N, Cin, H, W, seed=55)           # pre-BN tensor of the BatchNorm whose backward is fused
+    g = torch.Generator().manual_seed(56)
+    scale, shift = torch.rand(G, Cin, generator=g) + 0.5, torch.randn(G, Cin, generator=g) * 0.3
+    mean, rstd = torch.randn(G, Cin, generator=g) * 0.2, torch.rand(G, Cin, generator=g) + 0.5
+    coef = torch.stack([scale, shift, mean, rstd], 1).contiguous()          # [G][4][Cin]
+    e5 = lambda t: t.view(G, 1, Cin, 1, 1)
+    yv = ybn.view(G, ipg, Cin, H, W)
+    signsrc = rnd(torch.bfloat16, N, Cin, H, W, seed=57)
+    if mode == 2:
+        m = ((yv * e5(scale) + e5(shift)) > 0).float()
+    elif mode == 3:
+        m = (signsrc > 0).float().view(G, ipg, Cin, H, W)
+    else:
+        m = torch.ones(G, ipg, Cin, H, W)
+    gm_ref = g_ref.view(G, ipg, Cin, H, W) * m
+    s1_ref = gm_ref.sum((1, 3, 4))
+    s2_ref = (gm_ref * (yv - e5(mean)) * e5(rstd)).sum((1, 3, 4))
+    # ---- the launch(es)
+    dyd, yd, srcd = ops.to_nhwc(dy, torch.bfloat16), ops.to_nhwc(ybn, torch.bfloat16), ops.to_nhwc(base, torch.bfloat16)
+    bits = pack_sign_bits(ops.to_nhwc(signsrc, torch.bfloat16))
+    dx = torch.zeros(N, H, W, Cin, dtype=torch.bfloat16, device="cuda")
+    bstats = torch.zeros(L.STAT_REPLICAS, G, 2, Cin, device="cuda")
+    coef_d = coef.cuda()
+    Ho, Wo, pad = yo.shape[2], yo.shape[3], k // 2
+    keep, launched = [], 0
+    classes = [(0, 0)] if s == 1 else [(a, b) for a in range(2) for b in range(2)]
+    for (ph, pw) in classes:
+        if s == 1:
+            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), L.BF16, N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, H, W,
+                           k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, ipg, 1 if acc else 0, 0, 0)
+            mode_s, cls = "dgrad", (0, 0)
+        else:
+            ta, _, dh0 = ops.s2_class(k, pad, ph)
+            tb, _, dw0 = ops.s2_class(k, pad, pw)
+            Hl, Wl = (H - ph + 1) // 2, (W - pw + 1) // 2
+            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), L.BF16, N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, Hl, Wl,
+                           ta, tb, dh0, dw0, 1, 2, 2, ph, pw, 0, ipg, 1 if acc else 0, 0, 0)
+            mode_s, cls = "dgrad_s2", (ph, pw)
+        d.flags = L.CONV_WANT_FA
+        if L.conv_layout(d).fa != 1:
+            pytest.skip("no fusable geometry for this shape")
+        d.acc_src = srcd.data_ptr() if acc else 0
+        d.bn_y, d.bn_coef, d.bn_mask_mode, d.bn_bits = yd.data_ptr(), coef_d.data_ptr(), mode, bits.data_ptr() if mode == 3 else 0
+        wp = ops.pack_weight(w.cuda(), d, mode_s, cls)
+        keep.append(wp)
+        d.wp = wp.data_ptr()
+        L.call(L.lib.mfc_conv2d_fwd, d)
+        launched += 1
+    torch.cuda.synchronize()
+    gm = ops.to_nchw(dx, Cin).cpu().view(G, ipg, Cin, H, W)
+    assert relerr(gm, gm_ref) < 2 * TOL[torch.bfloat16]
+    st = bstats.sum(0).cpu()
+    assert relerr(st[:, 0], s1_ref) < 5 * TOL[torch.bfloat16]
+    assert relerr(st[:, 1], s2_ref) < 5 * TOL[torch.bfloat16]
+    # a launch that cannot take the fusion must refuse it rather than drop it
+    d2 = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), L.F32, N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, H, W,
+                    k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, ipg, 0, 0, 0)
+    d2.bn_y, d2.bn_coef, d2.wp = yd.data_ptr(), coef_d.data_ptr(), keep[0].data_ptr()
+    assert L.lib.mfc_conv2d_fwd(C.byref(d2), L.stream_ptr()) < 0
+
+
 WG_CASES = [(2, 48, 48, 3, 1, 24, 40), (2, 3, 64, 3, 2, 64, 96), (2, 96, 96, 3, 1, 30, 40), (3, 96, 192, 3, 2, 15, 20),
             (2, 384, 384, 3, 1, 15, 20), (2, 256, 64, 1, 1, 16, 24), (1, 720, 720, 1, 1, 12, 20), (2, 720, 5, 1, 1, 16, 24),
             (2, 15, 15, 11, 1, 32, 48), (1, 22, 15, 11, 1, 24, 40), (1, 48, 96, 3, 2, 23, 30), (2, 32, 64, 3, 1, 17, 21),
@@ -168,6 +250,43 @@ def test_conv_wgrad(M, case, dtype, tr):
     finally:
         L.lib.mfc_set_flag(1, 1)
     assert relerr(dw.cpu(), w.grad) < TOL[dtype]
+
+
+DMA_CASES = [(3, 32, 32, 15, 20), (2, 64, 32, 23, 30), (2, 32, 64, 5, 6), (4, 96, 96, 12, 40), (2, 32, 32, 4, 8), (6, 64, 64, 17, 9)]
+
+
+@pytest.mark.parametrize("xf", [False, True])
+@pytest.mark.parametrize("case", DMA_CASES)
+def test_wgrad_dma_kernel(M, case, xf):
+    """conv_wgrad_dma.hip (3x3 / stride 1, channel counts that are multiples of 32, bf16): ragged images (partial 4x8 sub-tiles on both
+    axes, images narrower than a tile, every tile an edge tile), several channel blocks, with and without the fused BatchNorm + ReLU
+    of the producer (two statistic groups); against autograd on the same bf16-rounded operands, and against the register-staged
+    kernel it replaces (mfc_set_flag(29, 0))."""
+    _, L, ops = M
+    N, Cin, Cout, H, W = case
+    G = 2 if N % 2 == 0 else 1
+    x = rnd(torch.bfloat16, N, Cin, H, W, seed=41)
+    xa, coef = x, None
+    if xf:
+        scale, shift = torch.rand(G, Cin) + 0.5, torch.randn(G, Cin) * 0.3
+        coef = torch.zeros(G, 4, Cin)
+        coef[:, 0], coef[:, 1] = scale, shift
+        xa = F.relu(x.view(G, N // G, Cin, H, W) * scale.view(G, 1, Cin, 1, 1) + shift.view(G, 1, Cin, 1, 1)).reshape(N, Cin, H, W)
+        xa = xa.bfloat16().float()
+    w = rnd(torch.bfloat16, Cout, Cin, 3, 3, seed=42, scale=0.05).requires_grad_(True)
+    y = F.conv2d(xa, w, None, padding=1)
+    dy = rnd(torch.bfloat16, *y.shape, seed=43)
+    y.backward(dy)
+    res = []
+    for flag in (1, 0):
+        L.lib.mfc_set_flag(29, flag)
+        try:
+            res.append(ops.conv2d_wgrad(ops.to_nhwc(x, torch.bfloat16), ops.to_nhwc(dy, torch.bfloat16), Cout, Cin, 3, 1,
+                                        in_coef=coef.cuda() if xf else None, in_relu=xf, ipg=N // G).cpu())
+        finally:
+            L.lib.mfc_set_flag(29, 1)
+    assert relerr(res[0], w.grad) < TOL[torch.bfloat16]
+    assert relerr(res[0], res[1]) < 1e-4            # same products, fp32 accumulation in another order
 
 
 def test_wgrad_fused_input_transform(M):
