@@ -260,7 +260,7 @@ def main():
                     optflow_inputs=args.optflow, depth_inputs=args.depth)
     model = model.to(device)
     model = model.eval() if args.fwd_only else model.train()
-    for env, attr in (("MFC_MASK_BITS", "relu_mask_bits"), ("MFC_BATCH_WGRAD", "batch_wgrad")):      # tuning switches of the plan
+    for env, attr in (("MFC_MASK_BITS", "relu_mask_bits"), ("MFC_BATCH_WGRAD", "batch_wgrad"), ("MFC_FUSE_BNRED", "fuse_bnbwd_reduce")):      # tuning switches of the plan
         if os.environ.get(env):
             setattr(model, attr, os.environ[env] != "0")
     opt = mfc.FlatAdam(model, lr=1e-4)

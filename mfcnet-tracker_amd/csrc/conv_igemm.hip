@@ -399,6 +399,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                 const bool bnm = FUSE && BF && p.bn_y != nullptr;                             // fused BatchNorm-backward statistics (wave-uniform)
                 const bool full = (i0 + p.TH <= p.Hl) && (j0 + p.TW <= p.Wl);
                 constexpr int NP = BF ? NT / 2 : 0;              // cout tile pairs stored transposed
+                // Fused data-gradient epilogue: ALL global reads of the tile epilogue (running sum, pre-BN tensor, mask bits) are issued up
+                // front, so their latency is paid once per tile and not once per 16-pixel row (issued next to their use they cost
+                // +11 us on a 23 us launch: 1-2 us of exposed latency per row, two workgroups per CU to hide it)
+                constexpr int NPF = (FUSE && BF) ? (NP > 0 ? NP : 1) : 1;
+                uint4 pf_old[FUSE ? MT : 1][NPF], pf_y[FUSE ? MT : 1][NPF]; unsigned pf_bits[FUSE ? MT : 1][NPF];
+                if constexpr (FUSE && BF) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bool vpx = pin[mt] && (full || ((i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl)));
+#pragma unroll
+                        for (int pr = 0; pr < NP; ++pr) {
+                            const bool vc = (n0 + pr * 32 + (lane >> 4) * 8) < p.Cout_p;
+                            const unsigned lo = (vpx && vc) ? (unsigned)(eoff16[mt] + pr * 64) : 0u;
+                            if (p.accumulate) pf_old[mt][pr] = *(const uint4*)(abase + lo);
+                            if (bnm) pf_y[mt][pr] = *(const uint4*)(p.bn_y + toff + lo);
+                            if (bnm && p.bn_mode == 3) pf_bits[mt][pr] = p.bn_bits[(toff + lo) >> 4];
+                        }
+                    }
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const bool vpx = pin[mt] && (full || ((i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl)));
@@ -425,7 +444,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                             const unsigned off = (unsigned)(eoff16[mt] + pr * 64);
                             const bool vc = (n0 + pr * 32 + (lane >> 4) * 8) < p.Cout_p;
                             uint4 oldq = make_uint4(0, 0, 0, 0);
-                            if (p.accumulate) oldq = *(const uint4*)(abase + ((vpx && vc) ? off : 0u));
+                            if constexpr (FUSE) { if (p.accumulate) oldq = pf_old[mt][pr]; }
+                            else { if (p.accumulate) oldq = *(const uint4*)(abase + ((vpx && vc) ? off : 0u)); }
                             if (p.accumulate || bnm) {
                                 // dgrad accumulation happens in fp32 on the transposed layout: expand, transpose, add, round once
                                 float w[8];
@@ -445,9 +465,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                                     // BatchNorm / ReLU backward of the tensor this launch completes: mask, store the MASKED gradient, and keep
                                     // sum g*m, sum g*m*yhat of the lane's 8 channels (what mfc_bnbwd_reduce would sweep the tensor for again)
                                     const bool live = vpx && vc;
-                                    const unsigned lo = live ? off : 0u;
                                     float yv[8];
-                                    Gran<T>::unpack(*(const uint4*)(p.bn_y + toff + lo), yv);
+                                    Gran<T>::unpack(pf_y[FUSE ? mt : 0][pr], yv);
                                     const int ch = min(n0 + pr * 32 + (lane >> 4) * 8, p.Cout_p - 8);
                                     const float* cf = p.bn_coef + (size_t)(n / p.ipg) * 4 * p.Cout_p + ch;
                                     const float4 m0 = *(const float4*)(cf + 2 * p.Cout_p), m1 = *(const float4*)(cf + 2 * p.Cout_p + 4);
@@ -464,7 +483,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
 #pragma unroll
                                         for (int e = 0; e < 8; ++e) mk |= ((yv[e] * sc8[e] + sh8[e]) > 0.f ? 1u : 0u) << e;
                                     } else if (p.bn_mode == 3) {
-                                        mk = p.bn_bits[(toff + lo) >> 4];          // one byte per 8-channel granule (mfc_combine_fwd)
+                                        mk = pf_bits[FUSE ? mt : 0][pr];           // one byte per 8-channel granule (mfc_combine_fwd)
                                     }
 #pragma unroll
                                     for (int e = 0; e < 8; ++e) {

@@ -339,13 +339,16 @@ struct LaneSet {
     hipStream_t as[MFC_ASYNC_STREAMS]; hipEvent_t aev[MFC_ASYNC_EVENTS], ajoin[MFC_ASYNC_STREAMS];
     hipEvent_t seg;          // recorded on the detached stream at the end of a program whose final join was deferred (mfc_wait_detached)
     bool pending;            // detached work of an earlier program has not been joined yet
+    bool lane_b;             // a second side lane with a hardware queue of its own was found by the probe (s[3])
     bool ready;
 };
 static LaneSet g_lanes[16];
 static int g_lanes_on = 3;       // bit 0: parallel-section lanes, bit 1: detached (async) records
 static int g_lane_streams = 3;   // streams the section lanes are folded onto (1 = main only; measured best: 3 + the detached stream, more co-running persistent kernels thrash); tuning: mfc_set_flag(12, n)
-static int g_lane_map[MFC_MAX_LANES + 1] = {0, 1, 2, 2, 1, 0, 0, 0, 0};   // lane -> stream (0 = fold by modulo).  Measured best for the 4 HRNet branches: the
-                                                                          // 120x160 and 15x20 branches on the main stream, the two middle ones on one side stream
+static int g_lane_map[MFC_MAX_LANES + 1] = {0, 1, 2, -3, 1, 0, 0, 0, 0};  // lane -> stream (0 = fold by modulo; -3 = stream 3 if the probe found a second side lane with a
+                                                                          // hardware queue of its own, else stream 2).  The 120x160 and 15x20 branches on the main stream, the two middle
+                                                                          // ones on a side stream each: with both on ONE side stream the main stream idled ~0.55 ms per 3-branch module
+                                                                          // forward and ~0.84 ms backward (tools/lane_timeline.py)
 int mfc_set_lane_streams(int n) {
     if (n >= 1000) {          // decimal digits = streams of lanes 1..4, e.g. 1223
         g_lane_map[1] = n / 1000 % 10; g_lane_map[2] = n / 100 % 10; g_lane_map[3] = n / 10 % 10; g_lane_map[4] = n % 10;
@@ -425,24 +428,37 @@ static LaneSet* lanes_for_device(hipStream_t caller = nullptr, bool may_probe = 
         for (int i = 0; i < MFC_ASYNC_STREAMS; ++i)
             if (hipEventCreateWithFlags(&L->ajoin[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&L->seg, hipEventDisableTiming) != hipSuccess) return nullptr;
-        L->pending = false;
+        L->pending = false; L->lane_b = false;
         for (int i = 0; i < MFC_ASYNC_EVENTS; ++i)
             if (hipEventCreateWithFlags(&L->aev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (may_probe && g_probe_streams && g_async_prio == 0) {
-            // candidates: every side stream made above.  s[2] <- the first one that overlaps with the caller's stream,
-            // as[0] <- the first other one that overlaps with the caller's stream AND with s[2]
-            hipStream_t* cand[MFC_MAX_LANES - 1 + MFC_ASYNC_STREAMS]; int nc = 0;
-            for (int i = 2; i <= MFC_MAX_LANES; ++i) cand[nc++] = &L->s[i];
-            for (int i = 0; i < MFC_ASYNC_STREAMS; ++i) cand[nc++] = &L->as[i];
+            // candidates: every side stream made above.  side lane A (s[2]) <- the first one that overlaps with the caller's stream;
+            // detached (as[0]) <- the first other one that overlaps with the caller's stream AND with lane A; side lane B (s[3]) <- the
+            // first other one that overlaps with all three (with the default 4 hardware queues: main, two side lanes, detached).
+            std::vector<hipStream_t> h;
+            for (int i = 2; i <= MFC_MAX_LANES; ++i) h.push_back(L->s[i]);
+            for (int i = 0; i < MFC_ASYNC_STREAMS; ++i) h.push_back(L->as[i]);
             static const bool dbg = getenv("MFC_DEBUG") != nullptr;
-            int pick_l = -1, pick_a = -1;
+            const int nc = (int)h.size();
+            int pick_l = -1, pick_a = -1, pick_3 = -1;
             for (int i = 0; i < nc && pick_l < 0; ++i)
-                if (streams_overlap(caller, *cand[i])) pick_l = i;
+                if (streams_overlap(caller, h[i])) pick_l = i;
             for (int i = 0; i < nc && pick_l >= 0 && pick_a < 0; ++i)
-                if (i != pick_l && streams_overlap(caller, *cand[i]) && streams_overlap(*cand[pick_l], *cand[i])) pick_a = i;
-            if (dbg) fprintf(stderr, "[mfc lanes] stream probe: side lane <- candidate %d, detached <- candidate %d (of %d)\n", pick_l, pick_a, nc);
-            if (pick_l >= 0) { hipStream_t t = L->s[2]; L->s[2] = *cand[pick_l]; *cand[pick_l] = t; if (pick_a == 0) pick_a = pick_l; }
-            if (pick_a >= 0) { hipStream_t t = L->as[0]; L->as[0] = *cand[pick_a]; *cand[pick_a] = t; }
+                if (i != pick_l && streams_overlap(caller, h[i]) && streams_overlap(h[pick_l], h[i])) pick_a = i;
+            for (int i = 0; i < nc && pick_a >= 0 && pick_3 < 0; ++i)
+                if (i != pick_l && i != pick_a && streams_overlap(caller, h[i]) && streams_overlap(h[pick_l], h[i]) && streams_overlap(h[pick_a], h[i])) pick_3 = i;
+            if (dbg) fprintf(stderr, "[mfc lanes] stream probe: side lane A <- candidate %d, detached <- candidate %d, side lane B <- candidate %d (of %d)\n", pick_l, pick_a, pick_3, nc);
+            // hand the picked streams to their roles, the rest fill the remaining slots in order
+            std::vector<hipStream_t> rest;
+            for (int i = 0; i < nc; ++i) if (i != pick_l && i != pick_a && i != pick_3) rest.push_back(h[i]);
+            size_t ri = 0;
+            auto take = [&](int pick) { return pick >= 0 ? h[pick] : rest[ri++]; };
+            L->s[2] = take(pick_l);
+            L->as[0] = take(pick_a);
+            L->s[3] = take(pick_3);
+            for (int i = 4; i <= MFC_MAX_LANES; ++i) L->s[i] = rest[ri++];
+            for (int i = 1; i < MFC_ASYNC_STREAMS; ++i) L->as[i] = rest[ri++];
+            L->lane_b = pick_3 >= 0;
         }
         L->ready = true;
     }
@@ -487,7 +503,7 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
     };
     for (int i = 0; i < n; ++i) {
         int lane = (multi && (g_lanes_on & 1)) ? (ops[i].lane & 0xff) : 0;
-        if (lane >= 1 && lane <= MFC_MAX_LANES && g_lane_map[lane]) lane = g_lane_map[lane];
+        if (lane >= 1 && lane <= MFC_MAX_LANES && g_lane_map[lane]) lane = g_lane_map[lane] == -3 ? ((L && L->lane_b) ? 3 : 2) : g_lane_map[lane];
         else if (lane > g_lane_streams) lane = (lane - 1) % g_lane_streams + 1;      // fold the lanes onto the streams in use
         bool detached = multi && (g_lanes_on & 2) && (ops[i].lane & MFC_LANE_ASYNC);
         // a detached UNPACK sums the slices of weight gradients launched before it on the detached stream: in order only if that is ONE stream
