@@ -432,7 +432,7 @@ int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the 
  *   4  conv: persistent workgroups per launch (512)  5  conv: ablation mask (0)                    6  conv: LDS budget KiB (80)
  *   7  wgrad: ablation mask (0)                      8  conv: cout-block-fastest unit order (-1 auto)
  *   9  lanes: bit 0 parallel-section lanes, bit 1 detached records (3); 0 = every record on the caller's stream
- *  10  detached streams in use (1)                  11  wgrad: target workgroups per launch (128; sizes the partial-sum slices)
+ *  10  detached streams in use (1)                  11  wgrad: target workgroups per launch (256; sizes the partial-sum slices)
  *  12  lane -> stream folding (n streams, or a 4-digit map such as 1221)   13  run detached records on side lane k (0 = own stream)
  *  14  program main stream = interpreter's own (0)  15  what-if: skip record kinds (bit mask, timing only)
  *  16  detached stream priority (0; read at stream creation)              17  wgrad: prefetch-distance-2 variant (0)

@@ -24,12 +24,11 @@ static int g_wgrad_deep = 0;          // prefetch-distance-2 wave kernel when a 
                                      // (35.7 -> 30.2 us), but its 308 VGPRs cannot share a SIMD with a conv wave (246), so next to the
                                      // critical chain the step gets SLOWER (546 -> 530 frames/s): off by default; mfc_set_flag(17, v)
 static int g_wgrad_maxpx = 6000;     // output pixels one workgroup may walk before the pixel axis is split beyond g_wgrad_blocks (0 = never); mfc_set_flag(21, n)
-int g_wgrad_blocks = 128;            // target workgroups per wave-kernel launch (S = blocks / Y).  Alone, 512 (2 per CU) is fastest; in the
-                                     // step the launches run on the detached stream next to the critical chain: fewer, longer-lived
-                                     // workgroups leave that chain more of every CU AND write fewer partial-sum slices (each launch
-                                     // writes blocks x its packed image, which the unpack reads back: 4.7 GB per step at 256).
-                                     // Measured on the step: 256 -> 575, 192 -> 582, 128 -> 586, 96 -> 579, 64 -> 556 frames/s (W32;
-                                     // W48 flat); tuning: mfc_set_flag(11, n)
+int g_wgrad_blocks = 256;            // target workgroups per wave-kernel / DMA-kernel launch (S = blocks / Y).  The launches run on the detached stream
+                                     // next to the critical chain.  Round 1 (register-staged kernel): 256 -> 575, 192 -> 582, 128 -> 586, 64 -> 556 frames/s.
+                                     // Round 2 (LDS-DMA ring kernel, fused BatchNorm-backward epilogues): 128 and 256 give the same step time
+                                     // (39.64 / 39.65 ms, tools/sweep_grid.sh) while the kernel alone is 1.5x faster at 256 (28.2 -> 18.7 us for
+                                     // 32 -> 32 at 120x160: two workgroups per CU hide each other's fix-up pass), so 256; tuning: mfc_set_flag(11, n)
 int mfc_conv_set_lds_kb(int v);
 int mfc_conv_set_ybfast(int v);
 int mfc_set_lanes(int on);
@@ -73,7 +72,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 27) { g_bnred_blocks = value > 0 ? value : 1024; return 0; }
     if (id == 28) return mfc_set_defer_join(value);
     if (id == 29) { g_wgrad_dma = value; return 0; }
-    if (id == 11) { g_wgrad_blocks = value > 0 ? value : 128; return 0; }
+    if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
 

@@ -25,14 +25,21 @@ def bf(t):
     return t.bfloat16().float()
 
 
+GEOM = ("dtype", "N", "Hin", "Win", "Cin_p", "Cin", "Hout", "Wout", "Cout_p", "Cout", "Hl", "Wl", "TA", "TB", "dh0", "dw0", "in_stride",
+        "out_sh", "out_sw", "out_oh", "out_ow", "in_relu", "images_per_group", "accumulate", "bn_mask_mode", "flags")
+
+
+def conv_key(d):
+    return tuple(getattr(d, n) for n in GEOM) + (bool(d.bias), bool(d.in_coef), bool(d.out_stats), bool(d.acc_src), bool(d.bn_y))
+
+
 def _fields(s, skip):
     return tuple(getattr(s, n) for n, _ in s._fields_[skip:])
 
 
 def node_key(ci):
-    f, g = ci.fwd, ci.wg
-    return (_fields(f, 6) + (bool(f.bias), bool(f.in_coef), bool(f.out_stats)),
-            tuple(_fields(d, 6) for d in ci.dgrad), _fields(g, 4) + (bool(g.in_coef),))
+    g = ci.wg
+    return (conv_key(ci.fwd), tuple(conv_key(d) for d in ci.dgrad), _fields(g, 4) + (bool(g.in_coef),))
 
 
 def unique_nodes(width, B=8, H=480, W=640, T=3):
@@ -112,25 +119,53 @@ def run_node(ci, L, ops, seed):
         assert relerr(st[:, 0, :Cout], yr.sum((1, 3, 4))) < 5 * TOL, ("stats sum", what)
         assert relerr(st[:, 1, :Cout], (yr * yr).sum((1, 3, 4))) < 5 * TOL, ("stats sumsq", what)
 
-    # ---- data-gradient launch(es): 1 for stride 1, 4 output-parity classes for stride 2
+    # ---- data-gradient launch(es): 1 for stride 1, 4 output-parity classes for stride 2 -- with the epilogue fusions the plan gave them
+    #      (mfc_conv_desc.acc_src: running sum read from another tensor; bn_y: BatchNorm-backward mask + statistics)
     dyd = nhwc(dy, f.Cout_p)
     if ci.dgrad:
-        acc = ci.dgrad[0].accumulate
+        d0 = ci.dgrad[0]
+        acc, from_src, fused, mode = d0.accumulate, bool(d0.acc_src), bool(d0.bn_y), d0.bn_mask_mode
         base = bf(torch.randn(N, Cin, Hin, Win, generator=g)) if acc else torch.zeros(N, Cin, Hin, Win)
-        dx = nhwc(base, f.Cin_p)
+        dx = nhwc(torch.zeros_like(base) if from_src else base, f.Cin_p)
+        srcd = nhwc(base, f.Cin_p) if from_src else None
+        ref = xa.grad + base
+        if fused:
+            ybn = bf(torch.randn(N, Cin, Hin, Win, generator=g))
+            signsrc = bf(torch.randn(N, Cin, Hin, Win, generator=g))
+            sc2, sh2 = torch.rand(G, Cin, generator=g) + 0.5, torch.randn(G, Cin, generator=g) * 0.3
+            mean, rstd = torch.randn(G, Cin, generator=g) * 0.2, torch.rand(G, Cin, generator=g) + 0.5
+            cf2 = torch.zeros(G, 4, f.Cin_p)
+            cf2[:, 0, :Cin], cf2[:, 1, :Cin], cf2[:, 2, :Cin], cf2[:, 3, :Cin] = sc2, sh2, mean, rstd
+            e5 = lambda t: t.view(G, 1, Cin, 1, 1)
+            yv = ybn.view(G, ipg, Cin, Hin, Win)
+            m = ((yv * e5(sc2) + e5(sh2)) > 0).float() if mode == 2 else (signsrc > 0).float().view(G, ipg, Cin, Hin, Win) if mode == 3 \
+                else torch.ones(G, ipg, Cin, Hin, Win)
+            gm_ref = ref.view(G, ipg, Cin, Hin, Win) * m
+            s1_ref, s2_ref = gm_ref.sum((1, 3, 4)), (gm_ref * (yv - e5(mean)) * e5(rstd)).sum((1, 3, 4))
+            ref = gm_ref.view(N, Cin, Hin, Win)
+            yd2, cf2d = nhwc(ybn, f.Cin_p), cf2.cuda()
+            sgn = nhwc(signsrc, f.Cin_p)
+            bits = ((sgn.float() > 0).to(torch.int32).reshape(-1, 8) * torch.tensor([1 << e for e in range(8)], dtype=torch.int32, device="cuda")).sum(1).to(torch.uint8).contiguous()
+            bst = torch.zeros(L.STAT_REPLICAS, G, 2, f.Cin_p, device="cuda")
         keep = []
         for dg in ci.dgrad:
             q = clone_desc(dg)
             q.inp, q.out, q.bias, q.in_coef, q.out_stats = dyd.data_ptr(), dx.data_ptr(), 0, 0, 0
-            mode, cls = ("dgrad", (0, 0)) if s == 1 else ("dgrad_s2", (q.out_oh, q.out_ow))
-            wq = ops.pack_weight(w.cuda(), q, mode, cls)
+            q.acc_src = srcd.data_ptr() if from_src else 0
+            if fused:
+                q.bn_y, q.bn_coef, q.out_stats, q.bn_bits = yd2.data_ptr(), cf2d.data_ptr(), bst.data_ptr(), bits.data_ptr() if mode == 3 else 0
+            mode_s, cls = ("dgrad", (0, 0)) if s == 1 else ("dgrad_s2", (q.out_oh, q.out_ow))
+            wq = ops.pack_weight(w.cuda(), q, mode_s, cls)
             keep.append(wq)
             q.wp = wq.data_ptr()
             L.call(L.lib.mfc_conv2d_fwd, q)
         torch.cuda.synchronize()
-        ref = xa.grad + base
         e = relerr(nchw(dx, Cin), ref)
-        assert e < (2 if acc else 1) * TOL, ("dgrad", what, e)
+        assert e < (2 if (acc or fused) else 1) * TOL, ("dgrad", what, e, fused, mode, from_src)
+        if fused:
+            st = bst.sum(0).cpu()
+            assert relerr(st[:, 0, :Cin], s1_ref) < 5 * TOL, ("dgrad fused sum g*m", what)
+            assert relerr(st[:, 1, :Cin], s2_ref) < 5 * TOL, ("dgrad fused sum g*m*yhat", what)
 
     # ---- weight-gradient launch (+ unpack of its partial-sum slices)
     wg = clone_desc(ci.wg)
@@ -154,6 +189,9 @@ def test_every_conv_node_of_the_benchmarked_plan(width):
         pytest.skip("needs a GPU")
     from mfcnet_amd import _lib as L, ops
     nodes = unique_nodes(width)
-    assert 30 <= len(nodes) <= 60
+    assert 30 <= len(nodes) <= 80
     done = [run_node(ci, L, ops, 100 + i) for i, ci in enumerate(nodes)]
-    print(f"w{width}: {len(done)} distinct convolution nodes (fwd + dgrad + wgrad) of the B=8 480x640 bf16 plan match CPU fp32")
+    nfused = sum(1 for ci in nodes if ci.dgrad and ci.dgrad[0].bn_y)
+    assert nfused >= (10 if width == 32 else 4)          # the fused data-gradient epilogues of the plan are among them
+    print(f"w{width}: {len(done)} distinct convolution nodes (fwd + dgrad + wgrad; {nfused} with a fused BatchNorm-backward epilogue) "
+          f"of the B=8 480x640 bf16 plan match CPU fp32")
