@@ -52,7 +52,7 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     _need_gpu()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + SMALL
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-prof"] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     d = _json_line(r.stdout)
@@ -66,7 +66,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     """`python bench.py --gpus 2` (the driver's form, no torchrun): the parent starts two ranks before touching the GPU and relays
     rank 0's line, which must report two ranks; a launcher whose world size disagrees with --gpus is refused."""
     _need_gpu()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + SMALL,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-prof"] + SMALL,
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     d = _json_line(r.stdout)
