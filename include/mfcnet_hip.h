@@ -224,13 +224,36 @@ typedef struct {
 typedef struct {
     mfc_view out;
     mfc_view src[4];
-    int32_t nsrc, relu, dtype;
+    int32_t nsrc, relu, dtype;   /* relu: 0 none, 1 ReLU, 2 SiLU (x * sigmoid(x), the ResUnet_VB activation) */
     int32_t N, C;            /* C: channels in the slice (multiple of granule size or padded) */
     int32_t images_per_group;
     uint64_t maskbits;       /* optional (bf16): uint8 [N*H*W*out.Cp/8], bit e of byte (pixel*Cp + c)/8 = out[pixel][c + e] > 0 -- the
                               * ReLU mask the BatchNorm backward of the summed terms reads (mask_mode 3) instead of the whole tensor */
 } mfc_combine_desc;
 int mfc_combine_fwd(const mfc_combine_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ResUnet_VB building blocks (models/resunet.py:46-76: WeightStandardizedConv2d -> GroupNorm -> SiLU), inference.
+ *   mfc_ws_normalize:  w'[o] = (w[o] - mean_o) * rsqrt(var_o + eps) over the cin*kh*kw weights of output channel o (biased variance,
+ *                      resunet.py:55-60); the standardised weights then go through mfc_pack_weights / mfc_conv2d_fwd like any others.
+ *   mfc_gn_finalize:   GroupNorm coefficients from the per-(image, channel) sums a convolution launched with images_per_group = 1
+ *                      accumulated: per image n and channel group g, mean / rstd over C/groups channels x H x W; coef[n][0][c] = gamma_c * rstd,
+ *                      coef[n][1][c] = beta_c - mean * scale, [2] = mean, [3] = rstd -- the layout of the BatchNorm coefficient block, so the
+ *                      consumers apply it the same way (mfc_combine_desc.relu = 2 adds SiLU: x * sigmoid(x), resunet.py:67).
+ *   mfc_upsample_nearest2x: nn.Upsample(scale_factor = 2, mode = 'nearest') (resunet.py:34-38), NHWC.
+ * ------------------------------------------------------------------------------------ */
+int mfc_ws_normalize(const float* w, float* w_out, int32_t Cout, int32_t per_out, float eps, void* stream);
+typedef struct {
+    const float* stats;      /* [MFC_STAT_REPLICAS][N][2][Cp] */
+    float* coef;             /* out [N][4][Cp] */
+    const float* gamma;      /* [C] */
+    const float* beta;       /* [C] */
+    int32_t C, Cp, N, groups;
+    float count;             /* H * W */
+    float eps;
+} mfc_gnfin_desc;
+int mfc_gn_finalize(const mfc_gnfin_desc* d, void* stream);
+int mfc_upsample_nearest2x(const void* src, void* dst, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t Cp, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm / ReLU backward (precedent: inplace_abn_cuda.cu:174-292 edz_eydz + backward).
@@ -375,7 +398,10 @@ typedef enum {
     MFC_OP_BIAS_GRAD = 11, MFC_OP_MEMSET = 12, MFC_OP_PACK = 13, MFC_OP_UNPACK = 14, MFC_OP_NCHW2NHWC = 15,
     MFC_OP_NHWC2NCHW = 16,
     MFC_OP_WGRAD_BATCH = 17,     /* raw.a = HOST pointer to an mfc_wgrad_desc array (kept alive by the caller), raw.i[0] = n */
-    MFC_OP_BNFIN_BATCH = 18      /* raw.a = DEVICE pointer to an mfc_bnfin_desc array, raw.i[0] = n, raw.i[1] = max Cp */
+    MFC_OP_BNFIN_BATCH = 18,     /* raw.a = DEVICE pointer to an mfc_bnfin_desc array, raw.i[0] = n, raw.i[1] = max Cp */
+    MFC_OP_WSNORM = 19,          /* raw.a = w, raw.b = w_out, raw.i[0] = Cout, raw.i[1] = per_out, raw.i[2] = eps (float bits) */
+    MFC_OP_GNFIN = 20,           /* gnfin */
+    MFC_OP_UPNEAR = 21           /* raw.a = src, raw.b = dst, raw.i = dtype, N, H, W, Cp */
 } mfc_op_kind;
 
 #define MFC_LANE_ASYNC 0x100
@@ -390,6 +416,7 @@ typedef struct {
         mfc_conv_desc conv;
         mfc_wgrad_desc wgrad;
         mfc_bnfin_desc bnfin;
+        mfc_gnfin_desc gnfin;
         mfc_combine_desc combine;
         mfc_bnbwd_desc bnbwd;
         mfc_bnbwdfin_desc bnbwdfin;

@@ -104,6 +104,9 @@ extern "C" int mfc_bn_finalize_batch(const mfc_bnfin_desc* table_dev, int32_t n,
     return MFC_OK;
 }
 
+// SiLU (nn.SiLU, resunet.py:67): x * sigmoid(x)
+__device__ inline float silu_f(float x) { return x / (1.f + __expf(-x)); }
+
 // ------------------------------------------------------------------ combine forward
 template <typename T>
 __device__ inline void load_gran_f(const mfc_view& v, int n, int h, int w, int ch, float* f) {
@@ -149,9 +152,12 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, lo
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] += f[e];
     }
-    if (d.relu) {
+    if (d.relu == 1) {
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = relu_nan(acc[e]);
+    } else if (d.relu == 2) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = silu_f(acc[e]);
     }
     *(uint4*)((char*)d.out.ptr + ((((size_t)n * d.out.H + h) * d.out.W + w) * d.out.Cp + d.out.c_off + g * E) * sizeof(T)) = Gran<T>::pack(acc);
     if constexpr (E == 8) {
@@ -202,9 +208,12 @@ __global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, l
                 for (int e = 0; e < E; ++e) acc[e] += f[e];
             }
         }
-        if (d.relu) {
+        if (d.relu == 1) {
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] = relu_nan(acc[e]);
+        } else if (d.relu == 2) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = silu_f(acc[e]);
         }
         *(uint4*)((char*)d.out.ptr + ((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(acc);
         if constexpr (E == 8) {
@@ -1207,6 +1216,89 @@ extern "C" int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, 
     if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, (bf16_t*)dlogits, (const float*)dU, total);
     else hipLaunchKernelGGL(head_gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, (float*)dlogits, (const float*)dU, total);
     MFC_PROF_END(st);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+
+// ------------------------------------------------------------------ ResUnet_VB pieces (models/resunet.py), inference
+// one workgroup per output channel: biased mean / variance of its cin*kh*kw weights in fp64, then the standardised weights
+__global__ __launch_bounds__(256) void ws_normalize_kernel(const float* w, float* wo, int per_out, float eps) {
+    __shared__ double rs[256], rq[256];
+    const float* src = w + (size_t)blockIdx.x * per_out;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < per_out; i += 256) { const double v = (double)src[i]; s += v; q += v * v; }
+    rs[threadIdx.x] = s; rq[threadIdx.x] = q;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) { rs[threadIdx.x] += rs[threadIdx.x + h]; rq[threadIdx.x] += rq[threadIdx.x + h]; }
+        __syncthreads();
+    }
+    const double mean = rs[0] / per_out;
+    double var = rq[0] / per_out - mean * mean; if (var < 0.0) var = 0.0;
+    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+    for (int i = threadIdx.x; i < per_out; i += 256) wo[(size_t)blockIdx.x * per_out + i] = (src[i] - m) * r;
+}
+extern "C" int mfc_ws_normalize(const float* w, float* w_out, int32_t Cout, int32_t per_out, float eps, void* stream) {
+    if (!w || !w_out || Cout <= 0 || per_out <= 0) return MFC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(ws_normalize_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, w_out, per_out, eps);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// GroupNorm coefficients: grid (channel groups, N); a workgroup sums the replica rows of its group's channels, then writes scale / shift
+__global__ __launch_bounds__(256) void gn_finalize_kernel(mfc_gnfin_desc d) {
+    __shared__ double rs[256], rq[256];
+    const int g = blockIdx.x, n = blockIdx.y, cpg = d.C / d.groups;
+    const size_t rstride = (size_t)d.N * 2 * d.Cp;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < cpg * MFC_R; i += 256) {
+        const int c = g * cpg + i % cpg, r = i / cpg;
+        s += (double)d.stats[(size_t)r * rstride + ((size_t)n * 2 + 0) * d.Cp + c];
+        q += (double)d.stats[(size_t)r * rstride + ((size_t)n * 2 + 1) * d.Cp + c];
+    }
+    rs[threadIdx.x] = s; rq[threadIdx.x] = q;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) { rs[threadIdx.x] += rs[threadIdx.x + h]; rq[threadIdx.x] += rq[threadIdx.x + h]; }
+        __syncthreads();
+    }
+    const double cnt = (double)d.count * cpg;
+    const double mean = rs[0] / cnt;
+    double var = rq[0] / cnt - mean * mean; if (var < 0.0) var = 0.0;
+    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)d.eps));
+    for (int i = threadIdx.x; i < cpg; i += 256) {
+        const int c = g * cpg + i;
+        float* cf = d.coef + (size_t)n * 4 * d.Cp + c;
+        const float scale = d.gamma[c] * r;
+        cf[0] = scale; cf[d.Cp] = d.beta[c] - m * scale; cf[2 * d.Cp] = m; cf[3 * d.Cp] = r;
+    }
+}
+extern "C" int mfc_gn_finalize(const mfc_gnfin_desc* d, void* stream) {
+    if (!d || !d->stats || !d->coef || !d->gamma || !d->beta || d->C <= 0 || d->C > d->Cp || d->N <= 0 || d->groups <= 0 || d->C % d->groups || d->count <= 0.f)
+        return MFC_ERR_INVALID_ARG;
+    if (d->N > 65535) return MFC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->groups, d->N), dim3(256), 0, (hipStream_t)stream, *d);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// nearest-neighbour x2: dst[n, h, w, :] = src[n, h / 2, w / 2, :]; one thread per destination granule
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_nearest2x_kernel(const char* src, char* dst, int H, int W, int Cg, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % Cg); long pix = idx / Cg;
+    const int w = (int)(pix % (2 * W)); pix /= (2 * W);
+    const int h = (int)(pix % (2 * H)); const long n = pix / (2 * H);
+    *(uint4*)(dst + idx * 16) = *(const uint4*)(src + ((((size_t)n * H + (h >> 1)) * W + (w >> 1)) * Cg + g) * 16);
+}
+extern "C" int mfc_upsample_nearest2x(const void* src, void* dst, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t Cp, void* stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || Cp <= 0 || Cp % 8 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
+    const int Cg = Cp / (dtype == MFC_BF16 ? 8 : 4);
+    const long total = (long)N * 2 * H * 2 * W * Cg;
+    hipLaunchKernelGGL(upsample_nearest2x_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, (char*)dst, H, W, Cg, total);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

@@ -318,6 +318,13 @@ static int run_one(const mfc_op& o, void* stream) {
         case MFC_OP_NHWC2NCHW:   // a = src, b = dst, i = dtype,N,C,H,W,Cp
             return mfc_nhwc_to_nchw((const void*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3],
                                     o.u.raw.i[4], o.u.raw.i[5], stream);
+        case MFC_OP_WSNORM: {    // a = w, b = w_out, i[0] = Cout, i[1] = per_out, i[2] = eps (float bits)
+            float eps; memcpy(&eps, &o.u.raw.i[2], 4);
+            return mfc_ws_normalize((const float*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], eps, stream);
+        }
+        case MFC_OP_GNFIN: return mfc_gn_finalize(&o.u.gnfin, stream);
+        case MFC_OP_UPNEAR:      // a = src, b = dst, i = dtype, N, H, W, Cp
+            return mfc_upsample_nearest2x((const void*)o.u.raw.a, (void*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3], o.u.raw.i[4], stream);
         default: return MFC_ERR_INVALID_ARG;
     }
 }

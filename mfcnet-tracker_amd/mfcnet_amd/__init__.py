@@ -6,6 +6,7 @@ Drop-in for the reference's `models.get_multiframe_segmentation_model` on the
 from ._lib import BF16, F32, MfcError, lib  # noqa: F401  (importing loads libmfcnet_hip.so or raises)
 from .model import (HighResolutionNetHIP, HRNetMultiBasic, HRNetMultiLarge, get_multiframe_segmentation_model,  # noqa: F401
                     get_tooltip_segmentation_model)
+from .resunet import ResUnet_VB  # noqa: F401
 from .optim import FlatAdam  # noqa: F401
 from .loss import mfc_loss  # noqa: F401
 from .metrics import confusion_counts, get_metrics  # noqa: F401

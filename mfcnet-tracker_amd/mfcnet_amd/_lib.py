@@ -25,6 +25,7 @@ LANE_ASYNC = 0x100
 OP_HEAD_FWD, OP_HEAD_BWD, OP_BIAS_GRAD, OP_MEMSET, OP_PACK, OP_UNPACK, OP_NCHW2NHWC, OP_NHWC2NCHW = range(9, 17)
 OP_WGRAD_BATCH = 17
 OP_BNFIN_BATCH = 18
+OP_WSNORM, OP_GNFIN, OP_UPNEAR = 19, 20, 21
 WGRAD_MAXBATCH = 8
 CONV_WANT_FA = 1
 
@@ -71,6 +72,11 @@ class BnFinDesc(C.Structure):
     _fields_ = [("stats", vp), ("coef", vp), ("gamma", vp), ("beta", vp), ("running_mean", vp),
                 ("running_var", vp), ("num_batches_tracked", vp),
                 ("C", i32), ("Cp", i32), ("G", i32), ("training", i32), ("count", f32), ("eps", f32), ("momentum", f32)]
+
+
+class GnFinDesc(C.Structure):
+    _fields_ = [("stats", vp), ("coef", vp), ("gamma", vp), ("beta", vp), ("C", i32), ("Cp", i32), ("N", i32), ("groups", i32),
+                ("count", f32), ("eps", f32)]
 
 
 class View(C.Structure):
@@ -122,7 +128,7 @@ class RawOp(C.Structure):
 
 
 class OpUnion(C.Union):
-    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("bnfin", BnFinDesc), ("combine", CombineDesc),
+    _fields_ = [("conv", ConvDesc), ("wgrad", WgradDesc), ("bnfin", BnFinDesc), ("gnfin", GnFinDesc), ("combine", CombineDesc),
                 ("bnbwd", BnBwdDesc), ("bnbwdfin", BnBwdFinDesc), ("maskadd", MaskAddDesc), ("head", HeadDesc),
                 ("headbwd", HeadBwd), ("raw", RawOp), ("bytes", C.c_uint8 * 248)]
 
@@ -133,7 +139,7 @@ class Op(C.Structure):
 
 # every symbol include/mfcnet_hip.h declares
 EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_conv2d_wgrad_parts", "mfc_conv2d_wgrad_batch", "mfc_unpack_wgrad",
-           "mfc_bn_finalize", "mfc_bn_finalize_batch", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
+           "mfc_bn_finalize", "mfc_bn_finalize_batch", "mfc_ws_normalize", "mfc_gn_finalize", "mfc_upsample_nearest2x", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd", "mfc_confusion_counts", "mfc_adam_step", "mfc_program_run", "mfc_wait_detached", "mfc_program_profile", "mfc_graph_capture", "mfc_graph_launch", "mfc_graph_destroy",
            "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect", "mfc_prof_dump"]
@@ -174,6 +180,9 @@ def _load():
                  "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd"):
         getattr(lib, name).argtypes = [vp, vp]
     lib.mfc_bn_finalize_batch.argtypes = [vp, i32, i32, vp]
+    lib.mfc_ws_normalize.argtypes = [vp, vp, i32, i32, f32, vp]
+    lib.mfc_gn_finalize.argtypes = [vp, vp]
+    lib.mfc_upsample_nearest2x.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.mfc_conv2d_lds_bytes.argtypes = [vp]
     lib.mfc_conv2d_wgrad_parts.argtypes = [vp]
     lib.mfc_conv2d_wgrad_batch.argtypes = [vp, i32, vp]

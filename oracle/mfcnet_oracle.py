@@ -623,3 +623,102 @@ def train_step(net: Net, opt, frames, mask, optflow=None, depth=None, **loss_kw)
     loss.backward()
     opt.step()
     return out.detach(), {k: float(v) for k, v in parts.items()}
+
+
+# --------------------------------------------------------------------------
+# ResUnet_VB (models/resunet.py:97-180): weight-standardised 3x3 conv + GroupNorm + SiLU residual U-Net.
+# Dead code in the reference (nothing constructs it) but named by SURVEY.md 8(f) rank 4 as an alternative base; restated here
+# functionally (inference), keyed by the reference's state_dict names, and pinned by tests/golden/resunet_vb_eval.npz.
+# --------------------------------------------------------------------------
+def resunet_table(channels=3, dim=16, out_dim=5, dim_mults=(1, 2, 4, 8), init_dim=None):
+    """(name, shape, kind) in the reference's registration order (resunet.py:107-155)."""
+    init_dim = init_dim or dim
+    dims = [init_dim] + [dim * m for m in dim_mults]
+    in_out = list(zip(dims[:-1], dims[1:]))
+    t = []
+
+    def conv(name, cout, cin, k):
+        t.append((name + ".weight", (cout, cin, k, k), "conv_w"))
+        t.append((name + ".bias", (cout,), "conv_b"))
+
+    def block(name, cin, cout):                      # Block: proj (WS conv 3x3) + GroupNorm, resunet.py:62-76
+        conv(name + ".proj", cout, cin, 3)
+        t.append((name + ".norm.weight", (cout,), "bn_gamma"))
+        t.append((name + ".norm.bias", (cout,), "bn_beta"))
+
+    def resblock(name, cin, cout):                   # resunet.py:78-95
+        block(name + ".block1", cin, cout)
+        block(name + ".block2", cout, cout)
+        if cin != cout:
+            conv(name + ".res_conv", cout, cin, 1)
+
+    conv("init_conv", init_dim, channels, 7)
+    n = len(in_out)
+    for i, (ci, co) in enumerate(in_out):
+        resblock(f"downs.{i}.0", ci, ci)
+        if i < n - 1:
+            conv(f"downs.{i}.1.1", co, ci * 4, 1)     # Downsample = Sequential(Rearrange, Conv2d 1x1), :40-44
+        else:
+            conv(f"downs.{i}.1", co, ci, 3)
+    for i, (ci, co) in enumerate(reversed(in_out)):   # (self.ups is registered before self.mid_block: resunet.py:121-122, 135)
+        resblock(f"ups.{i}.0", co + ci, co)
+        if i < n - 1:
+            conv(f"ups.{i}.1.1", ci, co, 3)           # Upsample = Sequential(nn.Upsample, Conv2d 3x3), :34-38
+        else:
+            conv(f"ups.{i}.1", ci, co, 3)
+    resblock("mid_block", dims[-1], dims[-1])
+    resblock("final_res_block", dim * 2, dim)
+    conv("output_layer", out_dim, dim, 1)
+    return t
+
+
+def resunet_forward(sd, x, dim=16, dim_mults=(1, 2, 4, 8), groups=8, init_dim=None):
+    """resunet.py:157-180 with the module tree flattened; sd = {name: tensor} as resunet_table lists them."""
+    init_dim = init_dim or dim
+    dims = [init_dim] + [dim * m for m in dim_mults]
+    in_out = list(zip(dims[:-1], dims[1:]))
+
+    def ws_conv(x, name):                            # WeightStandardizedConv2d.forward, :50-60 (fp32: eps 1e-5)
+        w = sd[name + ".weight"]
+        mean = w.mean(dim=(1, 2, 3), keepdim=True)
+        var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+        return F.conv2d(x, (w - mean) * (var + 1e-5).rsqrt(), sd[name + ".bias"], padding=1)
+
+    def block(x, name):
+        y = ws_conv(x, name + ".proj")
+        y = F.group_norm(y, groups, sd[name + ".norm.weight"], sd[name + ".norm.bias"], 1e-5)
+        return F.silu(y)
+
+    def resblock(x, name):
+        h = block(block(x, name + ".block1"), name + ".block2")
+        if name + ".res_conv.weight" in sd:
+            return h + F.conv2d(x, sd[name + ".res_conv.weight"], sd[name + ".res_conv.bias"])
+        return h + x
+
+    def conv(x, name, pad):
+        return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], padding=pad)
+
+    x = conv(x, "init_conv", 3)
+    r = x
+    hs = []
+    n = len(in_out)
+    for i in range(n):
+        x = resblock(x, f"downs.{i}.0")
+        hs.append(x)
+        if i < n - 1:                                # 'b c (h p1) (w p2) -> b (c p1 p2) h w', then 1x1
+            B, Cc, H, W = x.shape
+            x = x.view(B, Cc, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, Cc * 4, H // 2, W // 2)
+            x = conv(x, f"downs.{i}.1.1", 0)
+        else:
+            x = conv(x, f"downs.{i}.1", 1)
+    x = resblock(x, "mid_block")
+    for i in range(n):
+        x = torch.cat((x, hs.pop()), dim=1)
+        x = resblock(x, f"ups.{i}.0")
+        if i < n - 1:
+            x = conv(F.interpolate(x, scale_factor=2, mode="nearest"), f"ups.{i}.1.1", 1)
+        else:
+            x = conv(x, f"ups.{i}.1", 1)
+    x = torch.cat((x, r), dim=1)
+    x = resblock(x, "final_res_block")
+    return conv(x, "output_layer", 0)

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(L):
 
 def test_ctypes_mirrors_match_c_struct_sizes(L):
     structs = {"mfc_op": L.Op, "mfc_conv_desc": L.ConvDesc, "mfc_wgrad_desc": L.WgradDesc, "mfc_pack_job": L.PackJob,
-               "mfc_unpack_job": L.UnpackJob, "mfc_bnfin_desc": L.BnFinDesc, "mfc_view": L.View, "mfc_combine_desc": L.CombineDesc,
+               "mfc_unpack_job": L.UnpackJob, "mfc_bnfin_desc": L.BnFinDesc, "mfc_gnfin_desc": L.GnFinDesc, "mfc_view": L.View, "mfc_combine_desc": L.CombineDesc,
                "mfc_bnbwd_desc": L.BnBwdDesc, "mfc_bnbwdfin_desc": L.BnBwdFinDesc, "mfc_maskadd_desc": L.MaskAddDesc,
                "mfc_headgather_desc": L.HeadDesc, "mfc_loss_desc": L.LossDesc, "mfc_conv_layout": L.ConvLayout,
                "mfc_prof_entry": L.ProfEntry}
