@@ -22,9 +22,13 @@
  *     base_model once per frame with separate BatchNorm batches
  *     (models/multiframe_model.py:459-461);
  *   - functions return 0 on success, a negative mfc_status otherwise; they never
- *     throw, never allocate, never synchronise; all work is enqueued on `stream`
- *     (a hipStream_t; pass torch.cuda.current_stream().cuda_stream);
- *   - re-entrant per stream, no hidden global state.
+ *     throw, never allocate device memory, never synchronise (mfc_prof_collect / mfc_prof_dump / mfc_program_profile excepted);
+ *     all work is enqueued on `stream` (a hipStream_t; pass torch.cuda.current_stream().cuda_stream);
+ *   - the single-operation entry points keep no state between calls.  What IS process-wide: the tuning switches of mfc_set_flag (defaults
+ *     are the measured optima; no entry point of the product path changes them) and, per DEVICE, the interpreter's side streams / events
+ *     (mfc_program_run creates them on first use).  Consequently programs for one device must be issued from one host thread at a
+ *     time (two models may alternate; two threads may not interleave records of the same device).  Per-call behaviour is an argument
+ *     (mfc_program_run_ex), not a switch.  The model is not wrappable by nn.DataParallel (one process per GPU instead: INTEGRATION.md).
  */
 #ifndef MFCNET_HIP_H
 #define MFCNET_HIP_H
@@ -429,6 +433,10 @@ typedef struct {
 } mfc_op;
 /* runs ops[0..n); returns 0 or (-(1000*index) + status) of the first failing record */
 int mfc_program_run(const mfc_op* ops, int32_t n, void* stream);
+/* per-call options (nothing process-wide is touched): MFC_RUN_DEFER_JOIN -- the program does not join the detached stream at its end; the next
+ * program of the same step continues on it and the last one joins everything (backward segments of a data-parallel step, see mfc_wait_detached) */
+#define MFC_RUN_DEFER_JOIN 1u
+int mfc_program_run_ex(const mfc_op* ops, int32_t n, void* stream, uint32_t run_flags);
 /* hipGraph form of a program: capture once (the program must have run once before; `stream` must not be the null
  * stream; section lanes / detached records become parallel graph branches), replay with mfc_graph_launch.  All pointers in
  * the records are baked into the graph, which is what the static plan guarantees.  Measured on MI355X / ROCm 7.2: no faster
@@ -471,7 +479,8 @@ int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the 
  *  24  conv: smallest Cin and Cout sent to that GEMM (128)
  *  25  wgrad: 1x1 weight gradients without input transform as a split-K GEMM (wgrad_gemm1x1.hip) (1)
  *  26  wgrad: smallest Cin and Cout sent to that GEMM (64)           27  BN-backward reduce: workgroups per launch (1024; 512-2048 measured equal)
- *  28  program: defer the final join of the detached stream to the next program (0; set by the segmented backward)
+ *  28  program: defer the final join of the detached stream to the next program (0; tuning only -- the product path passes
+ *      MFC_RUN_DEFER_JOIN to mfc_program_run_ex instead)
  *  29  wgrad: 3x3 / stride-1 weight gradients of 32-channel-multiple layers through the LDS-DMA ring kernel (conv_wgrad_dma.hip) (1) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */

@@ -478,7 +478,14 @@ static bool g_capturing = false;      // (a captured program stays on the captur
 // MFC_OP_UNPACK / the program end -- the weight gradients.  Such a record waits (event) for everything issued so far on
 // the stream it would have run on, then runs on an extra stream, so the MFMA-bound wgrad launches overlap the HBM-bound
 // BatchNorm-backward sweeps and the data-gradient chain instead of sitting in it.
-extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
+static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_join);
+extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) { return program_run(ops, n, stream, g_defer_join != 0); }
+// the same with per-call options instead of process-wide switches: MFC_RUN_DEFER_JOIN = do not join the detached stream at the end (the
+// next program of the step continues on it; see mfc_wait_detached)
+extern "C" int mfc_program_run_ex(const mfc_op* ops, int32_t n, void* stream, uint32_t run_flags) {
+    return program_run(ops, n, stream, (run_flags & MFC_RUN_DEFER_JOIN) != 0);
+}
+static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_join) {
     if (!ops || n < 0) return MFC_ERR_INVALID_ARG;
     hipStream_t caller = (hipStream_t)stream;
     LaneSet* L = nullptr;
@@ -539,7 +546,7 @@ extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) {
         if (rc != MFC_OK) { if (in_par) join(); if (aused) join_async(); leave(); return -(1000 * (i + 1)) + rc; }
     }
     if (in_par) join();
-    const bool can_defer = g_defer_join && !g_capturing && g_async_n == 1 && !(g_async_on_lane >= 2 && g_async_on_lane <= MFC_MAX_LANES);
+    const bool can_defer = defer_join && !g_capturing && g_async_n == 1 && !(g_async_on_lane >= 2 && g_async_on_lane <= MFC_MAX_LANES);
     if (aused && can_defer) {
         // the caller continues with another program of the same step (backward segments): the detached stream is NOT joined here; an
         // event marks this point on it, for whoever needs the detached results so far (mfc_wait_detached), and the next program's

@@ -28,6 +28,7 @@ OP_BNFIN_BATCH = 18
 OP_WSNORM, OP_GNFIN, OP_UPNEAR = 19, 20, 21
 WGRAD_MAXBATCH = 8
 CONV_WANT_FA = 1
+RUN_DEFER_JOIN = 1
 
 i32, u64, f32, vp = C.c_int32, C.c_uint64, C.c_float, C.c_void_p
 
@@ -141,7 +142,7 @@ class Op(C.Structure):
 EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_conv2d_wgrad_parts", "mfc_conv2d_wgrad_batch", "mfc_unpack_wgrad",
            "mfc_bn_finalize", "mfc_bn_finalize_batch", "mfc_ws_normalize", "mfc_gn_finalize", "mfc_upsample_nearest2x", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
-           "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd", "mfc_confusion_counts", "mfc_adam_step", "mfc_program_run", "mfc_wait_detached", "mfc_program_profile", "mfc_graph_capture", "mfc_graph_launch", "mfc_graph_destroy",
+           "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd", "mfc_confusion_counts", "mfc_adam_step", "mfc_program_run", "mfc_program_run_ex", "mfc_wait_detached", "mfc_program_profile", "mfc_graph_capture", "mfc_graph_launch", "mfc_graph_destroy",
            "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect", "mfc_prof_dump"]
 
 
@@ -162,6 +163,7 @@ def _load():
         if name not in ("mfc_version",):
             getattr(lib, name).restype = C.c_int
     lib.mfc_program_run.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.mfc_program_run_ex.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32]
     lib.mfc_program_profile.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mfc_graph_capture.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mfc_wait_detached.argtypes = [C.c_void_p]

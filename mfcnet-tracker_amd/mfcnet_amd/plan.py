@@ -914,13 +914,7 @@ class Plan:
             # every segment but the last leaves the detached stream un-joined (the chain does not wait for the weight gradients of the
             # segment); the bucket's consumer orders itself after them with mfc_wait_detached
             defer = self.lanes and i + 1 < nseg
-            if defer:
-                L.lib.mfc_set_flag(28, 1)
-            try:
-                rc = L.lib.mfc_program_run(prog, len(prog), L.stream_ptr())
-            finally:
-                if defer:
-                    L.lib.mfc_set_flag(28, 0)
+            rc = L.lib.mfc_program_run_ex(prog, len(prog), L.stream_ptr(), L.RUN_DEFER_JOIN if defer else 0)
             if rc != 0:
                 raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
             if hook is not None:
