@@ -100,7 +100,7 @@ void mfc_prof_after(hipStream_t st);
 // name of a template instantiation, built once (function-static buffer)
 #define MFC_PROF_NAME(buf, ...) static char buf[120]; if (!buf[0]) snprintf(buf, sizeof(buf), __VA_ARGS__)
 // bracket an element-wise launch: MFC_PROF_EW(st, "kernel<%s>", tname, bytes) ... launch ... MFC_PROF_END(st)
-#define MFC_PROF_END(st) do { if (g_mfc_prof_on) mfc_prof_after(st); } while (0)
+#define MFC_PROF_END(st) do { if (g_mfc_prof_on == 1) mfc_prof_after(st); } while (0)
 template <typename T> inline const char* mfc_tname();
 template <> inline const char* mfc_tname<float>() { return "float"; }
 template <> inline const char* mfc_tname<bf16_t>() { return "__bf16"; }

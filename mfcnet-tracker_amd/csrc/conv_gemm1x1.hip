@@ -349,13 +349,13 @@ int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_mfc_prof_on) {
+    if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * k.M * (double)d->Cout * (double)d->Cin;
         const double bytes = (double)k.M * (k.Cin_p + k.Cout_p) * 2.0;
         mfc_prof_before(st, "conv_gemm1x1_kernel", flops, bytes);
     }
     hipLaunchKernelGGL(conv_gemm1x1_kernel, dim3(grid), dim3(512), G_LDS, st, k);
-    if (g_mfc_prof_on) mfc_prof_after(st);
+    if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

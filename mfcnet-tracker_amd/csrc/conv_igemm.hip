@@ -722,7 +722,9 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
                 // register budget (no spills: a spill in the prefetch path serialises it): wide N tiles keep fewer
                 // pixel tiles / prefetch pieces per thread
                 int pm_max = mt == 4 ? (NT == 6 ? 0 : NT == 4 ? 3 : 6) : (NT == 6 ? 4 : 10);
-                if (nw == 8) pm_max = mt == 4 ? (NT == 6 ? 0 : 3) : 4;          // (the 8-wave instantiations: <MT 4, PMAX 3> and <MT 2, PMAX 4>)
+                if (nw == 8) pm_max = mt == 4 ? (NT == 6 ? 0 : 3) : (NT <= 4 ? 6 : 4);      // (the 8-wave instantiations: <MT 4, PMAX 3>, <MT 2, PMAX 4> and,
+                                                                                              //  for NT <= 4, <MT 2, PMAX 6>: a 64-channel 3x3 then keeps ALL its weights
+                                                                                              //  in LDS and runs one stage of 144 MFMAs per wave and tile)
                 const size_t lds_cap = nw == 8 ? (size_t)156 * 1024 : (size_t)g_conv_lds_kb * 1024;
                 if (l > lds_cap || pm > pm_max || t.nslots > 256) continue;
                 if (want_fa && !conv_variant_fa(d->dtype, NT, mt, pm, nw)) continue;
@@ -767,7 +769,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
 // with the transposed 8-channel layout, the only one that implements acc_src / bn_y; even NT so that every cout tile has a partner).
 static bool conv_variant_fa(int dtype, int NT, int MT, int PM, int NW) {
     int PMAXt = 0;
-    if (dtype == MFC_BF16 && NW == 8) PMAXt = (NT != 6 && MT == 4 && PM <= 3) ? 3 : ((MT == 2 && PM <= 4) ? 4 : 0);
+    if (dtype == MFC_BF16 && NW == 8) PMAXt = (NT != 6 && MT == 4 && PM <= 3) ? 3 : ((MT == 2 && PM <= 4) ? 4 : ((MT == 2 && NT <= 4 && PM <= 6) ? 6 : 0));
     else if (NT == 6) PMAXt = (MT == 2 && PM <= 4) ? 4 : 0;
     else if (MT == 4) PMAXt = PM <= 3 ? 3 : ((NT <= 3 && PM <= 6) ? 6 : 0);
     else PMAXt = PM <= 4 ? 4 : 10;
@@ -783,7 +785,7 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT, MT, PMAX, NW, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_mfc_prof_on) {
+    if (g_mfc_prof_on == 1) {
         MFC_PROF_NAME(pname, "conv_igemm_kernel<%s, %d, %d, %d, %d, %s>", mfc_tname<T>(), NT, MT, PMAX, NW, FUSE ? "true" : "false");
         const double E = sizeof(T) == 2 ? 8.0 : 4.0;
         const double flops = 2.0 * k.N * k.Hl * k.Wl * (double)k.Cout * k.TA * k.TB * (k.Cin_g * E);
@@ -791,7 +793,7 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
         mfc_prof_before(st, pname, flops, bytes);
     }
     hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT, PMAX, NW, FUSE>), dim3(grid), dim3(NW * 64), lds, st, k);
-    if (g_mfc_prof_on) mfc_prof_after(st);
+    if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -833,6 +835,7 @@ static int conv_dispatch_fused(const ConvK& k, int MT, int PM, int NW, size_t ld
         if (NW == 8) {
             if constexpr (NT == 2) { if (MT == 4 && PM <= 3) return conv_launch<T, NT, 4, 3, 8, true>(k, lds, grid, st); }
             if (MT == 2 && PM <= 4) return conv_launch<T, NT, 2, 4, 8, true>(k, lds, grid, st);
+            if (MT == 2 && PM <= 6) return conv_launch<T, NT, 2, 6, 8, true>(k, lds, grid, st);
             return MFC_ERR_UNSUPPORTED;
         }
         if (MT == 4) {
@@ -858,6 +861,7 @@ static int conv_dispatch(const ConvK& k, int MT, int PM, int NW, size_t lds, int
             } else {
                 if (MT == 4 && PM <= 3) return conv_launch<T, NT, 4, 3, 8>(k, lds, grid, st);
                 if (MT == 2 && PM <= 4) return conv_launch<T, NT, 2, 4, 8>(k, lds, grid, st);
+                if constexpr (NT <= 4) { if (MT == 2 && PM <= 6) return conv_launch<T, NT, 2, 6, 8>(k, lds, grid, st); }
                 return MFC_ERR_UNSUPPORTED;
             }
         }

@@ -841,14 +841,14 @@ static int wgrad_launch(const WgradK& k, size_t lds, int Y, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, TPW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_mfc_prof_on) {
+    if (g_mfc_prof_on == 1) {
         MFC_PROF_NAME(pname, "conv_wgrad_kernel<%s, %d, %s>", mfc_tname<T>(), TPW, TR ? "true" : "false");
         const double flops = 2.0 * k.N * k.Hout * k.Wout * (double)k.Co16 * k.Ci16 * k.TA * k.TB;
         const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_p + (double)k.N * k.Hout * k.Wout * k.Cout_p) * sizeof(T);
         mfc_prof_before(st, pname, flops, bytes);
     }
     hipLaunchKernelGGL((conv_wgrad_kernel<T, TPW, TR>), dim3(k.splits, Y), dim3(256), lds, st, k);
-    if (g_mfc_prof_on) mfc_prof_after(st);
+    if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -860,14 +860,14 @@ static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st)
         (void)hipFuncSetAttribute((const void*)conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_mfc_prof_on) {
+    if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB;
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
         MFC_PROF_NAME(pname, "conv_wgrad_fast_kernel<%d, %d, %d, %s>", TB, WCO, WCI, BIG ? "true" : "false");
         mfc_prof_before(st, pname, flops, bytes);
     }
     hipLaunchKernelGGL((conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>), dim3(f.splits * Y), dim3(256), lds, st, f);
-    if (g_mfc_prof_on) mfc_prof_after(st);
+    if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -943,14 +943,14 @@ static int wgrad_wave_launch(const WgradW& f, const WgradBatch& tb, size_t lds, 
         (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_mfc_prof_on) {
+    if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB * tb.n;
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0 * tb.n;
         MFC_PROF_NAME(pname, "conv_wgrad_wave_kernel<%d, %d, %d, %d, %d, %d>", TAA, TB, WCO, WCI, XP, PF);
         mfc_prof_before(st, pname, flops, bytes);
     }
     hipLaunchKernelGGL((conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP, PF>), dim3(f.splits * Y * tb.n), dim3(256), lds, st, f, tb);
-    if (g_mfc_prof_on) mfc_prof_after(st);
+    if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

@@ -324,7 +324,7 @@ int wgrad_dma_launch(const mfc_wgrad_desc* d, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_mfc_prof_on) {
+    if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * f.N * f.H * f.W * (double)f.Co16 * f.Ci16 * 9.0;
         const double bytes = ((double)f.N * f.H * f.W * (f.Cin_p + f.Cout_p)) * 2.0;
         mfc_prof_before(st, xf ? "conv_wgrad_dma_kernel<true>" : "conv_wgrad_dma_kernel<false>", flops, bytes);
@@ -332,7 +332,7 @@ int wgrad_dma_launch(const mfc_wgrad_desc* d, hipStream_t st) {
     const int grid = f.splits * f.co_blocks * f.ci_blocks;
     if (xf) hipLaunchKernelGGL(conv_wgrad_dma_kernel<true>, dim3(grid), dim3(256), lds, st, f);
     else hipLaunchKernelGGL(conv_wgrad_dma_kernel<false>, dim3(grid), dim3(256), lds, st, f);
-    if (g_mfc_prof_on) mfc_prof_after(st);
+    if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

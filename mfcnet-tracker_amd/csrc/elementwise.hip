@@ -11,7 +11,7 @@
 
 // event-profiler bracket of an element-wise launch: the row is named like the kernel rocprofv3 reports; BYTES = the tensors the launch
 // must touch once (its algorithmic HBM traffic)
-#define EW_PROF(st, KERNEL, DTYPE, BYTES) do { if (g_mfc_prof_on) mfc_prof_before(st, (DTYPE) == MFC_BF16 ? KERNEL "<__bf16>" : KERNEL "<float>", 0.0, (double)(BYTES)); } while (0)
+#define EW_PROF(st, KERNEL, DTYPE, BYTES) do { if (g_mfc_prof_on == 1) mfc_prof_before(st, (DTYPE) == MFC_BF16 ? KERNEL "<__bf16>" : KERNEL "<float>", 0.0, (double)(BYTES)); } while (0)
 static inline double view_bytes(const mfc_view& v, int N, int C, int esz) { return v.ptr ? (double)N * v.H * v.W * C * esz : 0.0; }
 
 // ------------------------------------------------------------------ BN finalize
@@ -89,7 +89,7 @@ extern "C" int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream) {
     if (d->training && !d->stats) return MFC_ERR_INVALID_ARG;
     if (d->C <= 0 || d->C > d->Cp || d->G <= 0) return MFC_ERR_INVALID_ARG;
     if (d->G > 8) return MFC_ERR_UNSUPPORTED;
-    if (g_mfc_prof_on) mfc_prof_before((hipStream_t)stream, "bn_finalize_kernel", 0.0, d->training ? (double)MFC_R * d->G * 2 * d->Cp * 4 : 0.0);
+    if (g_mfc_prof_on == 1) mfc_prof_before((hipStream_t)stream, "bn_finalize_kernel", 0.0, d->training ? (double)MFC_R * d->G * 2 * d->Cp * 4 : 0.0);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->Cp + 63) / 64), dim3(256), 0, (hipStream_t)stream, *d);
     MFC_PROF_END((hipStream_t)stream);
     MFC_CHECK_LAUNCH();

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const mfc_unpack_job*
 
 extern "C" int mfc_unpack_wgrad(const mfc_unpack_job* jobs_dev, int32_t njobs, int32_t total_blocks, void* stream) {
     if (!jobs_dev || njobs <= 0 || total_blocks <= 0) return MFC_ERR_INVALID_ARG;
-    if (g_mfc_prof_on) mfc_prof_before((hipStream_t)stream, "unpack_wgrad_kernel", 0.0, 0.0);      // (bytes live in the device job table)
+    if (g_mfc_prof_on == 1) mfc_prof_before((hipStream_t)stream, "unpack_wgrad_kernel", 0.0, 0.0);      // (bytes live in the device job table)
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
     MFC_PROF_END((hipStream_t)stream);
     MFC_CHECK_LAUNCH();

@@ -212,7 +212,7 @@ extern "C" int mfc_adam_step(float* p, const float* g, float* m, float* v, int64
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     const long blocks = ((n + 3) / 4 + 255) / 256;
-    if (g_mfc_prof_on) mfc_prof_before((hipStream_t)stream, "adam_kernel", 0.0, 28.0 * (double)n);
+    if (g_mfc_prof_on == 1) mfc_prof_before((hipStream_t)stream, "adam_kernel", 0.0, 28.0 * (double)n);
     hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale);
     MFC_PROF_END((hipStream_t)stream);
     MFC_CHECK_LAUNCH();
@@ -226,7 +226,7 @@ extern "C" int mfc_adam_step(float* p, const float* g, float* m, float* v, int64
 #include <string.h>
 int g_mfc_prof_on = 0;
 namespace {
-struct ProfRec { hipEvent_t a, b; const char* name; double flops, bytes; hipStream_t st; };
+struct ProfRec { hipEvent_t a, b; const char* name; double flops, bytes; hipStream_t st; bool shared_a = false; };
 std::vector<ProfRec> g_log;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
@@ -240,6 +240,14 @@ void mfc_prof_before(hipStream_t st, const char* name, double flops, double byte
     g_log.push_back(r);
 }
 void mfc_prof_after(hipStream_t st) { (void)hipEventRecord(g_log.back().b, st); }
+// section spans (mfc_prof_enable(2)): a timed event now on `st` ...
+hipEvent_t mfc_prof_mark(hipStream_t st) { hipEvent_t e = get_event(); (void)hipEventRecord(e, st); return e; }
+// ... and a row from an earlier mark to now-on-`st`; `tag` travels in the flops column
+void mfc_prof_span(hipEvent_t from, hipStream_t st, const char* name, double tag) {
+    ProfRec r; r.a = from; r.b = get_event(); r.name = name; r.flops = tag; r.bytes = 0; r.st = st; r.shared_a = true;
+    (void)hipEventRecord(r.b, st);
+    g_log.push_back(r);
+}
 extern "C" int mfc_prof_enable(int on) { g_mfc_prof_on = on; return MFC_OK; }
 // Tuning aid: the recorded launches as a timeline (CSV: name, stream, start_us, end_us relative to the first recorded launch; event
 // timestamps are device-wide, so launches on different streams are comparable).  Clears the log like mfc_prof_collect.
@@ -257,10 +265,11 @@ extern "C" int mfc_prof_dump(const char* path) {
         int si = -1;
         for (size_t i = 0; i < streams.size() && si < 0; ++i) if (streams[i] == r.st) si = (int)i;
         if (si < 0) { si = (int)streams.size(); streams.push_back(r.st); }
-        fprintf(f, "\"%s\",%d,%.2f,%.2f\n", r.name, si, t0 * 1e3, t1 * 1e3);
+        if (r.shared_a) fprintf(f, "\"%s@%d\",%d,%.2f,%.2f\n", r.name, (int)r.flops, si, t0 * 1e3, t1 * 1e3);
+        else fprintf(f, "\"%s\",%d,%.2f,%.2f\n", r.name, si, t0 * 1e3, t1 * 1e3);
     }
     fclose(f);
-    for (auto& r : g_log) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    for (auto& r : g_log) { if (!r.shared_a) g_pool.push_back(r.a); g_pool.push_back(r.b); }
     g_log.clear();
     return MFC_OK;
 }
@@ -285,6 +294,8 @@ extern "C" int mfc_prof_collect(mfc_prof_entry* out, int32_t cap) {
     return n;
 }
 
+hipEvent_t mfc_prof_mark(hipStream_t st);
+void mfc_prof_span(hipEvent_t from, hipStream_t st, const char* name, double tag);
 // ------------------------------------------------------------------ program interpreter
 extern "C" int mfc_op_size(void) { return (int)sizeof(mfc_op); }
 extern "C" const char* mfc_version(void) { return "mfcnet_hip 0.1 (gfx950)"; }
@@ -347,6 +358,8 @@ struct LaneSet {
     hipEvent_t seg;          // recorded on the detached stream at the end of a program whose final join was deferred (mfc_wait_detached)
     bool pending;            // detached work of an earlier program has not been joined yet
     bool lane_b;             // a second side lane with a hardware queue of its own was found by the probe (s[3])
+    bool lane_c;             // ... and a third one (s[4]; needs GPU_MAX_HW_QUEUES >= 5)
+    hipEvent_t fork_t;       // (timed) event of the current section's fork, mfc_prof_enable(2)
     bool ready;
 };
 static LaneSet g_lanes[16];
@@ -355,7 +368,10 @@ static int g_lane_streams = 3;   // streams the section lanes are folded onto (1
 static int g_lane_map[MFC_MAX_LANES + 1] = {0, 1, 2, -3, 1, 0, 0, 0, 0};  // lane -> stream (0 = fold by modulo; -3 = stream 3 if the probe found a second side lane with a
                                                                           // hardware queue of its own, else stream 2).  The 120x160 and 15x20 branches on the main stream, the two middle
                                                                           // ones on a side stream each: with both on ONE side stream the main stream idled ~0.55 ms per 3-branch module
-                                                                          // forward and ~0.84 ms backward (tools/lane_timeline.py)
+                                                                          // forward and ~0.84 ms backward (tools/lane_timeline.py).  A FOURTH concurrent chain (the 15x20 branch on a
+                                                                          // stream / hardware queue of its own, GPU_MAX_HW_QUEUES >= 5, map 1234 or -4 here) costs 45 %
+                                                                          // of the step (40.2 -> 58 ms, tools/sweep_queues.sh): the persistent convolution launches of
+                                                                          // four chains queue behind each other on every CU.
 int mfc_set_lane_streams(int n) {
     if (n >= 1000) {          // decimal digits = streams of lanes 1..4, e.g. 1223
         g_lane_map[1] = n / 1000 % 10; g_lane_map[2] = n / 100 % 10; g_lane_map[3] = n / 10 % 10; g_lane_map[4] = n % 10;
@@ -435,7 +451,7 @@ static LaneSet* lanes_for_device(hipStream_t caller = nullptr, bool may_probe = 
         for (int i = 0; i < MFC_ASYNC_STREAMS; ++i)
             if (hipEventCreateWithFlags(&L->ajoin[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&L->seg, hipEventDisableTiming) != hipSuccess) return nullptr;
-        L->pending = false; L->lane_b = false;
+        L->pending = false; L->lane_b = false; L->lane_c = false;
         for (int i = 0; i < MFC_ASYNC_EVENTS; ++i)
             if (hipEventCreateWithFlags(&L->aev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (may_probe && g_probe_streams && g_async_prio == 0) {
@@ -447,25 +463,30 @@ static LaneSet* lanes_for_device(hipStream_t caller = nullptr, bool may_probe = 
             for (int i = 0; i < MFC_ASYNC_STREAMS; ++i) h.push_back(L->as[i]);
             static const bool dbg = getenv("MFC_DEBUG") != nullptr;
             const int nc = (int)h.size();
-            int pick_l = -1, pick_a = -1, pick_3 = -1;
+            int pick_l = -1, pick_a = -1, pick_3 = -1, pick_4 = -1;
             for (int i = 0; i < nc && pick_l < 0; ++i)
                 if (streams_overlap(caller, h[i])) pick_l = i;
             for (int i = 0; i < nc && pick_l >= 0 && pick_a < 0; ++i)
                 if (i != pick_l && streams_overlap(caller, h[i]) && streams_overlap(h[pick_l], h[i])) pick_a = i;
             for (int i = 0; i < nc && pick_a >= 0 && pick_3 < 0; ++i)
                 if (i != pick_l && i != pick_a && streams_overlap(caller, h[i]) && streams_overlap(h[pick_l], h[i]) && streams_overlap(h[pick_a], h[i])) pick_3 = i;
-            if (dbg) fprintf(stderr, "[mfc lanes] stream probe: side lane A <- candidate %d, detached <- candidate %d, side lane B <- candidate %d (of %d)\n", pick_l, pick_a, pick_3, nc);
+            // side lane C (s[4]): only with more hardware queues than HIP's default four (GPU_MAX_HW_QUEUES >= 5)
+            for (int i = 0; i < nc && pick_3 >= 0 && pick_4 < 0; ++i)
+                if (i != pick_l && i != pick_a && i != pick_3 && streams_overlap(caller, h[i]) && streams_overlap(h[pick_l], h[i]) &&
+                    streams_overlap(h[pick_a], h[i]) && streams_overlap(h[pick_3], h[i])) pick_4 = i;
+            if (dbg) fprintf(stderr, "[mfc lanes] stream probe: side lane A <- candidate %d, detached <- candidate %d, side lane B <- candidate %d, side lane C <- candidate %d (of %d)\n", pick_l, pick_a, pick_3, pick_4, nc);
             // hand the picked streams to their roles, the rest fill the remaining slots in order
             std::vector<hipStream_t> rest;
-            for (int i = 0; i < nc; ++i) if (i != pick_l && i != pick_a && i != pick_3) rest.push_back(h[i]);
+            for (int i = 0; i < nc; ++i) if (i != pick_l && i != pick_a && i != pick_3 && i != pick_4) rest.push_back(h[i]);
             size_t ri = 0;
             auto take = [&](int pick) { return pick >= 0 ? h[pick] : rest[ri++]; };
             L->s[2] = take(pick_l);
             L->as[0] = take(pick_a);
             L->s[3] = take(pick_3);
-            for (int i = 4; i <= MFC_MAX_LANES; ++i) L->s[i] = rest[ri++];
+            L->s[4] = take(pick_4);
+            for (int i = 5; i <= MFC_MAX_LANES; ++i) L->s[i] = rest[ri++];
             for (int i = 1; i < MFC_ASYNC_STREAMS; ++i) L->as[i] = rest[ri++];
-            L->lane_b = pick_3 >= 0;
+            L->lane_b = pick_3 >= 0; L->lane_c = pick_4 >= 0;
         }
         L->ready = true;
     }
@@ -499,7 +520,18 @@ static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_jo
     bool in_par = false; unsigned used = 0;
     unsigned aused = (L && L->pending) ? 1u : 0u;     // detached work left over from a program that deferred its join: same stream, in order
     int anext = 0, aevn = 0;
+    // mfc_prof_enable(2): no per-launch events; instead one timeline row per parallel section and lane ("section <first record> lane <l>":
+    // from the fork to the last record of that lane) -- a handful of events per module, so the step is not perturbed (tools/lane_sections.py)
+    int sec_first = 0;
     auto join = [&]() {
+        if (g_mfc_prof_on == 2) {
+            static char names[MFC_MAX_LANES + 1][32];
+            for (int l = 1; l <= MFC_MAX_LANES; ++l)
+                if (l == 1 || (used & (1u << l))) {
+                    snprintf(names[l], sizeof(names[l]), "lane%d", l);
+                    mfc_prof_span(L->fork_t, l == 1 ? mainst : L->s[l], names[l], (double)sec_first);
+                }
+        }
         for (int l = 2; l <= MFC_MAX_LANES; ++l)
             if (used & (1u << l)) { (void)hipEventRecord(L->join[l], L->s[l]); (void)hipStreamWaitEvent(mainst, L->join[l], 0); }
         in_par = false; used = 0;
@@ -517,7 +549,7 @@ static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_jo
     };
     for (int i = 0; i < n; ++i) {
         int lane = (multi && (g_lanes_on & 1)) ? (ops[i].lane & 0xff) : 0;
-        if (lane >= 1 && lane <= MFC_MAX_LANES && g_lane_map[lane]) lane = g_lane_map[lane] == -3 ? ((L && L->lane_b) ? 3 : 2) : g_lane_map[lane];
+        if (lane >= 1 && lane <= MFC_MAX_LANES && g_lane_map[lane]) lane = g_lane_map[lane] == -3 ? ((L && L->lane_b) ? 3 : 2) : g_lane_map[lane] == -4 ? ((L && L->lane_c) ? 4 : 1) : g_lane_map[lane];
         else if (lane > g_lane_streams) lane = (lane - 1) % g_lane_streams + 1;      // fold the lanes onto the streams in use
         bool detached = multi && (g_lanes_on & 2) && (ops[i].lane & MFC_LANE_ASYNC);
         // a detached UNPACK sums the slices of weight gradients launched before it on the detached stream: in order only if that is ONE stream
@@ -525,11 +557,11 @@ static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_jo
         if (ops[i].kind == MFC_OP_UNPACK && !detached) lane = 0;      // (then it is ordinary serial work: joins the side lanes and the detached stream)
         hipStream_t st = mainst;
         if (lane >= 2 && lane <= MFC_MAX_LANES) {
-            if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; }
+            if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; sec_first = i; if (g_mfc_prof_on == 2) L->fork_t = mfc_prof_mark(mainst); }
             if (!(used & (1u << lane))) { (void)hipStreamWaitEvent(L->s[lane], L->fork, 0); used |= 1u << lane; }
             st = L->s[lane];
         } else if (lane == 1) {
-            if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; }
+            if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; sec_first = i; if (g_mfc_prof_on == 2) L->fork_t = mfc_prof_mark(mainst); }
         } else if (in_par) {
             join();
         }

@@ -215,13 +215,13 @@ int wgrad_gemm1x1_launch(const mfc_wgrad_desc* d, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)wgrad_gemm1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_mfc_prof_on) {
+    if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * k.M * (double)k.Co16 * k.Ci16;
         const double bytes = (double)k.M * (k.Cin_p + k.Cout_p) * 2.0;
         mfc_prof_before(st, "wgrad_gemm1x1_kernel", flops, bytes);
     }
     hipLaunchKernelGGL(wgrad_gemm1x1_kernel, dim3(k.co_blocks * k.ci_blocks * k.S), dim3(512), WG_LDS, st, k);
-    if (g_mfc_prof_on) mfc_prof_after(st);
+    if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
