@@ -643,7 +643,20 @@ static bool conv_variant_fa(int dtype, int NT, int MT, int PM, int NW);
 
 static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid, int& NWsel, int pass = 0) {
     // pass 0 honours MFC_CONV_WANT_FA (fusable geometries only); if none exists the search is repeated unrestricted (pass 1)
-    const bool want_fa = pass == 0 && (d->flags & MFC_CONV_WANT_FA) && d->dtype == MFC_BF16;
+    bool want_fa = pass == 0 && (d->flags & MFC_CONV_WANT_FA) && d->dtype == MFC_BF16;
+    if (want_fa) {
+        // only where the fused epilogue's cout blocking (NT in {2, 4}) is also the natural one: for 48 / 96 / 192 / 384 channels (HRNet-W48)
+        // the natural blocks are 3 or 6 tiles wide, and splitting them into blocks of 2 / 4 costs more than the fused reduce pass saves
+        // (96 -> 96 at 60x80: 73 us fused in three blocks vs 39.5 us + a 20 us reduce pass)
+        const int n16n = ceil_div(d->Cout, 16);
+        const int cand[5] = {6, 4, 3, 2, 1};
+        double bestc = 1e30; int ntn = 1;
+        for (int i = 0; i < 5; ++i) {
+            double c = (double)ceil_div(n16n, cand[i]) * cand[i] * (1.0 + 0.5 / cand[i]);
+            if (c < bestc - 1e-9) { bestc = c; ntn = cand[i]; }
+        }
+        if (ntn != 2 && ntn != 4) want_fa = false;
+    }
     if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
     if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
     const int E = d->dtype == MFC_BF16 ? 8 : 4;
