@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no `roofline` object)")
     ap.add_argument("--serial", action="store_true", help="one stream: no branch lanes / detached weight-gradient streams (for kernel profiles)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the data-parallel step path even with one rank "
+                    "(exercises the RCCL code path -- process-group options, bucket all-reduces, loss-sum all-reduce -- on a one-GPU box)")
     return ap.parse_args()
 
 
@@ -216,8 +218,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29577")):      # (--force-dist without a launcher)
+            os.environ.setdefault(k, v)
+        if args.force_dist:
+            os.environ["MFC_DIST_FORCE"] = "1"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             # RCCL's stream from the high-priority pool: those streams have hardware queues of their own, so the bucket
@@ -267,7 +273,7 @@ def main():
     frames, mask, depth, flow = synth(B, T, H, W, nc, 42 + 2000 + rank, device, args.depth, args.optflow)
 
     # (MFC_FORCE_BUCKETS: run the segmented backward + bucket hook on one GPU too, to measure what the segmentation costs)
-    reducer = GradBucketReducer(model, average=False) if (world > 1 or os.environ.get("MFC_FORCE_BUCKETS")) else None
+    reducer = GradBucketReducer(model, average=False) if (world > 1 or args.force_dist or os.environ.get("MFC_FORCE_BUCKETS")) else None
 
     def fwd():
         return model(frames[0]) if args.single else model(frames, optflow=flow, depth=depth)

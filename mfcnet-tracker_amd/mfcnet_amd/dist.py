@@ -12,13 +12,21 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
 LOSS_SUMS = 26      # acc[0:26] of mfc_loss_partial are the batch sums; acc[26:29] are derived by mfc_loss_finalize
+
+
+def _active(group=None):
+    """collectives are issued when a process group exists and has more than one rank -- or, for rehearsing the RCCL code path on a
+    one-GPU box, also with a single rank when MFC_DIST_FORCE=1 (bench.py --force-dist)"""
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("MFC_DIST_FORCE") == "1")
 
 
 def allreduce_loss_sums(acc: torch.Tensor, group=None):
     """SUM the loss partial sums (weighted NLL numerator / denominator, per-class I, sum p, sum [t==c]) over the ranks:
     the reference computes both loss terms on the gathered batch (src/engine.py:64-66, src/loss.py:57-58)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(acc[:LOSS_SUMS], op=dist.ReduceOp.SUM, group=group)
     return acc
 
@@ -30,7 +38,7 @@ def allreduce_grads(model, world_size=None, bucket_mb: int = 64, group=None, ave
     if not dist.is_initialized():
         return
     world_size = world_size or dist.get_world_size(group)
-    if world_size == 1:
+    if world_size == 1 and not _active(group):
         return
     g = model._G
     n = g.numel()
@@ -73,7 +81,7 @@ class GradBucketReducer:
 
     def _on_bucket(self, lo, hi):
         self.ranges.append((lo, hi))
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not _active(self.group):
             return
         sl = self.model._G[lo:hi]
         avg = self.average and dist.get_backend(self.group) == "nccl"

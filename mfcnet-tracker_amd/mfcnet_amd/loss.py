@@ -62,7 +62,8 @@ def mfc_loss(logits, target, class_weights=DEFAULT_CLASS_WEIGHTS, w_nll=0.7, w_j
     g = None
     if global_batch:
         import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        from .dist import _active
+        if _active(group):
             g = group if group is not None else True
     loss, acc = _LossFn.apply(logits, target, cw, float(w_nll), float(w_jac), g)
     if check_labels and float(acc[29]) > 0:

@@ -89,3 +89,18 @@ def test_overlapped_bucket_allreduce_equals_the_plain_order():
     print(r.stdout[-3000:])
     print(r.stderr[-3000:])
     assert r.returncode == 0 and "OVERLAP_CHECK ok=1" in r.stdout
+
+
+def test_bench_rccl_path_with_one_rank():
+    """`--force-dist`: the data-parallel step on RCCL (backend nccl) with a single rank -- process-group options (high-priority stream),
+    the all-gather of devices, the loss-sum all-reduce between mfc_loss_partial and _finalize, the per-bucket all-reduces started from
+    inside the segmented backward on a side stream (mfc_wait_detached), finish(), barrier, teardown.  One-GPU boxes cannot run N > 1 on
+    RCCL, so this is the only place these calls meet the real backend before the driver's scaling run."""
+    _need_gpu()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--no-prof"] + SMALL, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and 0.0 < d["config"]["final_loss"] < 20.0
+    ref = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-prof"] + SMALL, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert abs(_json_line(ref.stdout)["config"]["final_loss"] - d["config"]["final_loss"]) < 5e-3      # same step, SUM over one rank
