@@ -59,6 +59,17 @@ __device__ inline float row16_sum(float v) {
 // prefetch-issue / barrier cost -- halves)
 // FUSE: the data-gradient epilogue fusions (acc_src / bn_y) are compiled in (FA variants only; a separate instantiation, so that
 // the register allocation of the plain kernels is untouched)
+#ifdef MFC_CONV_TRACE
+// diagnostic build only (make TRACE=1, never shipped): s_memtime stamps of wave 0 of one workgroup; tools/trace_conv.py prints them
+__device__ long long g_conv_trace[4096];
+#define TR(tag) do { if (tr_on && tr_n < 2040) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (lane == 0) { g_conv_trace[2 * tr_n] = (tag); g_conv_trace[2 * tr_n + 1] = (long long)t_; } ++tr_n; } } while (0)
+extern "C" int mfc_conv_trace_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_trace), sizeof(long long) * 4096) == hipSuccess ? 0 : -1; }
+#else
+#define TR(tag) do {} while (0)
+#endif
+
 template <typename T, int NT, int MT, int PMAX, int NW, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(ConvK p) {
     constexpr int E = Gran<T>::E;
@@ -73,6 +84,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+#ifdef MFC_CONV_TRACE
+    const bool tr_on = (blockIdx.x == gridDim.x / 2 + 3) && wave == 0; int tr_n = 0;
+#endif
     const int u0 = Lb * p.per_block;
     const int nun = min(p.per_block, p.nunits - u0);
     if (nun <= 0) return;
@@ -297,6 +311,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
     };
 
     // ---------------- prologue ----------------
+    TR(0);
     UC uc = uc_init(u0), uc2 = uc;
     const int wstride = p.npieces * 1024;
     if (p.wres) {
@@ -308,6 +323,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
     store_patch();
     dma_wait();
     __syncthreads();
+    TR(1);
 
     if (p.ablate & 32) return;
     const bool resident = (p.nchunks == 1 && p.nstg == 1 && p.Yblocks == 1) || p.wres;
@@ -321,6 +337,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
         if (nxt && !resident && !(p.ablate & 1)) dma_w(uc2, c2, a2, smem + (((g + 1) & 1) ? p.off_w1 : p.off_w0));
         if (newpatch && !(p.ablate & 2)) load_patch(uc2, c2);
         if (red_pending) stats_flush();
+        TR(2);
 
         // ---------------- compute stage (tl, c, a) ----------------
         {
@@ -383,6 +400,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
             }
         }
 
+        TR(3);
         // ---------------- tile epilogue ----------------
         if (c == p.nchunks - 1 && a == p.nstg - 1 && !(p.ablate & 64)) {
             const int n = uc.n, i0 = uc.tyi * p.TH, j0 = uc.txi * p.TW, yb = uc.yb;
@@ -595,15 +613,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
         }
 
         // ---------------- hand over to the next stage ----------------
+        TR(4);
         if (newpatch) {
             __syncthreads();           // every wave has finished reading the current patch
+            TR(5);
             if (!(p.ablate & 2)) store_patch();
+            TR(6);
         }
         if (!resident) dma_wait();     // the weight DMA of stage g+1 has landed (this wave's pieces) ...
+        TR(7);
         __syncthreads();               // ... and everybody's
+        TR(8);
         tl = tl2; c = c2; a = a2; uc = uc2;
     }
     if (red_pending) stats_flush();
+#ifdef MFC_CONV_TRACE
+    TR(9);
+    if (tr_on && lane == 0) g_conv_trace[4095] = tr_n;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
 import torch
 from mfcnet_amd import _lib as L, ops
 from sweep_conv2 import time_op
-for (N, Cin, Cout, k, H, W) in [(24, 32, 32, 3, 120, 160), (24, 64, 64, 3, 60, 80), (24, 128, 128, 3, 30, 40), (24, 256, 256, 3, 15, 20)]:
+for (N, Cin, Cout, k, H, W) in [(24, 32, 32, 3, 120, 160), (24, 64, 64, 3, 60, 80), (24, 128, 128, 3, 30, 40), (24, 256, 256, 3, 15, 20),
+                               (24, 48, 48, 3, 120, 160), (24, 96, 96, 3, 60, 80), (24, 192, 192, 3, 30, 40), (24, 384, 384, 3, 15, 20)]:
     pad = k // 2
     x = torch.randn(N, H, W, ops.rup(Cin, 8), device="cuda").to(torch.bfloat16)
     w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05

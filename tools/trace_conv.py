@@ -1,11 +1,12 @@
-"""(debug build only) cycle trace of one workgroup of the conv kernel."""
+"""(diagnostic build only: `make -C mfcnet-tracker_amd/csrc TRACE=1`) cycle trace of wave 0 of one workgroup of the conv kernel."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
 import torch
 from mfcnet_amd import _lib as L, ops
 NAMES = {13: "epi: tile base done", 14: "epi: row start", 10: "loop top", 11: "dma issued", 12: "patch loads issued", 0: "start", 1: "prologue done", 2: "stage top (prefetch issued)", 3: "k-loop done", 4: "epilogue done", 5: "barrier A", 6: "patch stored", 7: "dma waited", 8: "barrier B", 9: "end"}
-for (N, Cin, Cout, k, H, W, xf) in [(24, 32, 32, 3, 120, 160, 0)]:
+SHAPES = [(24, 32, 32, 3, 120, 160, 0), (24, 64, 64, 3, 60, 80, 0), (24, 128, 128, 3, 30, 40, 0), (24, 48, 48, 3, 120, 160, 0), (24, 96, 96, 3, 60, 80, 0), (24, 192, 192, 3, 30, 40, 0), (24, 384, 384, 3, 15, 20, 0)]
+for (N, Cin, Cout, k, H, W, xf) in SHAPES:
     pad = k // 2
     x = torch.randn(N, H, W, ops.rup(Cin, 8), device="cuda").to(torch.bfloat16)
     w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
@@ -22,7 +23,7 @@ for (N, Cin, Cout, k, H, W, xf) in [(24, 32, 32, 3, 120, 160, 0)]:
     print(f"--- {(N,Cin,Cout,k,H,W)} : {n} trace points")
     t0 = buf[1]
     prev = t0
-    for i in range(min(n, 34)):
+    for i in range(min(n, int(os.environ.get('TRACE_POINTS', '40')))):
         tag, t = buf[2 * i], buf[2 * i + 1]
         print(f"  {t - t0:8d} (+{t - prev:6d})  {NAMES.get(tag, tag)}")
         prev = t
