@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBPS = 8000.0                              # HBM3E, MI355X_MICROARCH.md
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 
 
 def parse_args():
@@ -45,7 +45,8 @@ def parse_args():
     ap.add_argument("--basic", action="store_true", help="model_type HRNetMulti-Basic (flow warp) instead of HRNetMulti-Large")
     ap.add_argument("--single", action="store_true", help="single-frame HRNet (model_type 'HRNet'): one [B,3,H,W] tensor in (BASELINE.json configs[1])")
     ap.add_argument("--fwd-only", action="store_true", help="eval-mode forward only (no loss / backward / optimizer)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="storage type of activations / packed weights (fp16: IEEE half with a static loss scale, BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no `roofline` object)")
     ap.add_argument("--serial", action="store_true", help="one stream: no branch lanes / detached weight-gradient streams (for kernel profiles)")
@@ -278,6 +279,8 @@ def main():
     def fwd():
         return model(frames[0]) if args.single else model(frames, optflow=flow, depth=depth)
 
+    lscale = 1.0 if args.dtype != "fp16" else mfc.engine.loss_scale_for(model, torch.empty(B * max(world, 1), nc, H, W, device="meta"))
+
     def step():
         if args.fwd_only:
             with torch.no_grad():
@@ -285,10 +288,10 @@ def main():
         opt.zero_grad()
         out = fwd()
         loss, _ = mfc.mfc_loss(out, mask, global_batch=True)      # loss over the global batch (all-reduce of 26 sums), as the reference
-        loss.backward()                                             # (per-bucket all-reduces start inside, next to the backward kernels)
+        (loss * lscale if lscale != 1.0 else loss).backward()       # (per-bucket all-reduces start inside, next to the backward kernels)
         if reducer is not None:
             reducer.finish()                                        # ... so the ranks' gradients add up (SUM: global-batch loss)
-        opt.step()
+        opt.step(grad_scale=1.0 / lscale)
         return loss
 
     def sync():

@@ -13,10 +13,11 @@
  * Conventions
  *   - every pointer is a DEVICE pointer (tensor.data_ptr()); no torch types;
  *   - activations are NHWC with a padded channel pitch Cp (multiple of 8);
- *     element type T is float (MFC_F32, parity mode) or bf16 (MFC_BF16,
- *     throughput mode); statistics, coefficients, parameters, parameter
+ *     element type T is float (MFC_F32, parity mode), bf16 (MFC_BF16,
+ *     throughput mode) or IEEE half (MFC_F16: the same kernels, layouts and
+ *     fusions as bf16; training in it needs a loss scale); statistics, coefficients, parameters, parameter
  *     gradients and optimizer state are always fp32;
- *   - a "granule" is 16 bytes = 4 floats or 8 bf16 of one pixel;
+ *   - a "granule" is 16 bytes = 4 floats or 8 bf16 / fp16 of one pixel;
  *   - "groups": the T frames of a clip are batched as N = T*B images with
  *     G = T statistic groups (images_per_group = B), because the reference runs
  *     base_model once per frame with separate BatchNorm batches
@@ -39,7 +40,7 @@
 extern "C" {
 #endif
 
-typedef enum { MFC_F32 = 0, MFC_BF16 = 1 } mfc_dtype;
+typedef enum { MFC_F32 = 0, MFC_BF16 = 1, MFC_F16 = 2 } mfc_dtype;     /* F16: IEEE half storage, same kernels and layouts as BF16 */
 
 typedef enum {
     MFC_OK = 0,

@@ -5,7 +5,9 @@
 #include "mfcnet_hip.h"
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -58,12 +60,56 @@ template <> struct Gran<bf16_t> {
     }
 };
 
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ inline unsigned pack_f16x2(float lo, float hi) {       // RNE (v_cvt_pk_f16_f32 / two v_cvt_f16_f32), NaN and Inf kept
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+__device__ inline void unpack_f16x2(unsigned u, float& lo, float& hi) {
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, u);
+    lo = (float)h[0]; hi = (float)h[1];
+}
+// fp16 storage (BASELINE configs[4]): same granule shape as bf16; a training step in it needs the loss scale
+template <> struct Gran<f16_t> {
+    static constexpr int E = 8;
+    typedef uint2 Quad;
+    __device__ static inline void unquad(const uint2& v, float* f) { unpack_f16x2(v.x, f[0], f[1]); unpack_f16x2(v.y, f[2], f[3]); }
+    __device__ static inline uint2 quad(const float* f) { return make_uint2(pack_f16x2(f[0], f[1]), pack_f16x2(f[2], f[3])); }
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        unpack_f16x2(v.x, f[0], f[1]); unpack_f16x2(v.y, f[2], f[3]); unpack_f16x2(v.z, f[4], f[5]); unpack_f16x2(v.w, f[6], f[7]);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(pack_f16x2(f[0], f[1]), pack_f16x2(f[2], f[3]), pack_f16x2(f[4], f[5]), pack_f16x2(f[6], f[7]));
+    }
+};
+// two floats -> one dword of T (the 16-bit types)
+template <typename T> __device__ inline unsigned pack2(float lo, float hi);
+template <> __device__ inline unsigned pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ inline unsigned pack2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
+template <typename T> __device__ inline void unpack2(unsigned u, float& lo, float& hi);
+template <> __device__ inline void unpack2<bf16_t>(unsigned u, float& lo, float& hi) { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }
+template <> __device__ inline void unpack2<f16_t>(unsigned u, float& lo, float& hi) { unpack_f16x2(u, lo, hi); }
+// MFMA on 16-byte fragments held as raw bf16x8 registers (LDS reads are type-blind): the element type picks the instruction
+template <typename T> __device__ inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c);
+template <> __device__ inline f32x4 mfma16<bf16_t>(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+template <> __device__ inline f32x4 mfma16<f16_t>(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <typename T> __device__ inline f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c);
+template <> __device__ inline f32x16 mfma32<bf16_t>(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+template <> __device__ inline f32x16 mfma32<f16_t>(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 template <typename T> __device__ inline float ld_elem(const T* p);
 template <> __device__ inline float ld_elem<float>(const float* p) { return *p; }
 template <> __device__ inline float ld_elem<bf16_t>(const bf16_t* p) { return (float)*p; }
+template <> __device__ inline float ld_elem<f16_t>(const f16_t* p) { return (float)*p; }
 template <typename T> __device__ inline void st_elem(T* p, float v);
 template <> __device__ inline void st_elem<float>(float* p, float v) { *p = v; }
 template <> __device__ inline void st_elem<bf16_t>(bf16_t* p, float v) { *p = (bf16_t)v; }
+template <> __device__ inline void st_elem<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
 // logical ids so neighbouring tiles (shared halos / shared input patch across cout blocks)
@@ -104,6 +150,18 @@ void mfc_prof_after(hipStream_t st);
 template <typename T> inline const char* mfc_tname();
 template <> inline const char* mfc_tname<float>() { return "float"; }
 template <> inline const char* mfc_tname<bf16_t>() { return "__bf16"; }
+template <> inline const char* mfc_tname<f16_t>() { return "_Float16"; }
+static inline const char* mfc_dtname(int dtype) { return dtype == MFC_BF16 ? "__bf16" : (dtype == MFC_F16 ? "_Float16" : "float"); }
+static inline bool mfc_is16(int dtype) { return dtype == MFC_BF16 || dtype == MFC_F16; }
+static inline bool mfc_dtype_ok(int dtype) { return dtype == MFC_F32 || mfc_is16(dtype); }
+// run a statement with T bound to the element type of `dtype` (which the caller has validated)
+#define MFC_TYPED(dtype, T, ...) do { \
+    if ((dtype) == MFC_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+    else if ((dtype) == MFC_F16) { typedef f16_t T; __VA_ARGS__; } \
+    else { typedef float T; __VA_ARGS__; } } while (0)
+// the same for kernels that exist for the 16-bit types only
+#define MFC_TYPED16(dtype, T, ...) do { \
+    if ((dtype) == MFC_F16) { typedef f16_t T; __VA_ARGS__; } else { typedef bf16_t T; __VA_ARGS__; } } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #define MFC_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return MFC_ERR_LAUNCH; } while (0)

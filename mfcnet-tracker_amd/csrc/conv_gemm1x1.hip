@@ -52,6 +52,7 @@ constexpr int G_OFF_BIAS = G_OFF_COEF + G_COEF_FLOATS * 4;       // float [Cout 
 constexpr int G_BIAS_FLOATS = 1024;
 constexpr int G_LDS = G_OFF_BIAS + G_BIAS_FLOATS * 4;            // = 160 KiB
 
+template <typename TE>
 __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)(smem + G_OFF_RED);
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
             const int pl = idx >> 2, cg = cc * G_KG + hh * G_HG + ((idx & 3) ^ ((pl >> 1) & 3));
             if (cg < p.Cin_g) {
                 float f[8];
-                Gran<bf16_t>::unpack(*(const uint4*)(At + idx * 16), f);
+                Gran<TE>::unpack(*(const uint4*)(At + idx * 16), f);
                 const float4 s0 = *(const float4*)(sc + cg * 8), s1 = *(const float4*)(sc + cg * 8 + 4);
                 const float4 h0 = *(const float4*)(sc + p.Cin_p + cg * 8), h1 = *(const float4*)(sc + p.Cin_p + cg * 8 + 4);
                 const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
                     const float tv = f[e] * scv[e] + shv[e];
                     f[e] = p.in_relu ? relu_nan(tv) : tv;
                 }
-                *(uint4*)(At + idx * 16) = Gran<bf16_t>::pack(f);
+                *(uint4*)(At + idx * 16) = Gran<TE>::pack(f);
             }
         }
     };
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
             for (int nt = 0; nt < 4; ++nt)
                 if (nt < ntv) {
 #pragma unroll
-                    for (int mt = 0; mt < 8; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], x[mt], acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < 8; ++mt) acc[mt][nt] = mfma16<TE>(w[nt], x[mt], acc[mt][nt]);
                 }
         }
         // stage s + 1 has landed (this wave's pieces; the later ones may still be in flight), then everybody's
@@ -261,13 +262,13 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
                             t0[r] = x16[0]; t1[r] = x16[1];
                         }
                         float o8[8], w8[8];
-                        Gran<bf16_t>::unpack(oldq, o8);
+                        Gran<TE>::unpack(oldq, o8);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { w8[r] = __uint_as_float(t0[r]) + o8[r]; w8[4 + r] = __uint_as_float(t1[r]) + o8[4 + r]; }
-                        if (vc) *(uint4*)oaddr = Gran<bf16_t>::pack(w8);
+                        if (vc) *(uint4*)oaddr = Gran<TE>::pack(w8);
                     } else {
-                        const unsigned p0 = pack_bf16x2(v[2 * pr][0], v[2 * pr][1]), p1 = pack_bf16x2(v[2 * pr][2], v[2 * pr][3]);
-                        const unsigned q0 = pack_bf16x2(v[2 * pr + 1][0], v[2 * pr + 1][1]), q1 = pack_bf16x2(v[2 * pr + 1][2], v[2 * pr + 1][3]);
+                        const unsigned p0 = pack2<TE>(v[2 * pr][0], v[2 * pr][1]), p1 = pack2<TE>(v[2 * pr][2], v[2 * pr][3]);
+                        const unsigned q0 = pack2<TE>(v[2 * pr + 1][0], v[2 * pr + 1][1]), q1 = pack2<TE>(v[2 * pr + 1][2], v[2 * pr + 1][3]);
                         auto a32 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
                         auto a16 = __builtin_amdgcn_permlane16_swap(a32[0], a32[1], false, false);
                         auto b32 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
@@ -301,7 +302,7 @@ int g_conv_gemm = 1;                 // big 1x1 convolutions through conv_gemm1x
 int g_conv_gemm_minc = 128;          // smallest Cin / Cout (channels) sent there; tuning: mfc_set_flag(24, n)
 
 bool gemm1x1_eligible(const mfc_conv_desc* d) {
-    if (!g_conv_gemm || d->dtype != MFC_BF16) return false;
+    if (!g_conv_gemm || !mfc_is16(d->dtype)) return false;
     if (d->TA != 1 || d->TB != 1 || d->in_stride != 1 || d->dh0 != 0 || d->dw0 != 0) return false;
     if (d->out_sh != 1 || d->out_sw != 1 || d->out_oh != 0 || d->out_ow != 0) return false;
     if (d->Hl != d->Hout || d->Wl != d->Wout || d->Hin != d->Hout || d->Win != d->Wout) return false;
@@ -346,15 +347,16 @@ int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st) {
     k.px_per_group = grouped ? d->images_per_group * d->Hout * d->Wout : k.M;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * k.M * (double)d->Cout * (double)d->Cin;
         const double bytes = (double)k.M * (k.Cin_p + k.Cout_p) * 2.0;
-        mfc_prof_before(st, "conv_gemm1x1_kernel", flops, bytes);
+        mfc_prof_before(st, d->dtype == MFC_F16 ? "conv_gemm1x1_kernel<_Float16>" : "conv_gemm1x1_kernel<__bf16>", flops, bytes);
     }
-    hipLaunchKernelGGL(conv_gemm1x1_kernel, dim3(grid), dim3(512), G_LDS, st, k);
+    MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL(conv_gemm1x1_kernel<T_>, dim3(grid), dim3(512), G_LDS, st, k));
     if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;

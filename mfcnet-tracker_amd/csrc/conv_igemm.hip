@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], x[mt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = mfma16<T>(w[nt], x[mt], acc[mt][nt]);
                 };
                 ldx(xa, 0); ldw(wa, 0);
                 int ks = 0;
@@ -521,8 +521,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                                 }
                                 if (vpx && vc && !(p.ablate & 4)) *(uint4*)(tbase + off) = Gran<T>::pack(w);
                             } else {
-                                const unsigned p0 = pack_bf16x2(v[2 * pr][0], v[2 * pr][1]), p1 = pack_bf16x2(v[2 * pr][2], v[2 * pr][3]);
-                                const unsigned q0 = pack_bf16x2(v[2 * pr + 1][0], v[2 * pr + 1][1]), q1 = pack_bf16x2(v[2 * pr + 1][2], v[2 * pr + 1][3]);
+                                const unsigned p0 = pack2<T>(v[2 * pr][0], v[2 * pr][1]), p1 = pack2<T>(v[2 * pr][2], v[2 * pr][3]);
+                                const unsigned q0 = pack2<T>(v[2 * pr + 1][0], v[2 * pr + 1][1]), q1 = pack2<T>(v[2 * pr + 1][2], v[2 * pr + 1][3]);
                                 auto a32 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
                                 auto a16 = __builtin_amdgcn_permlane16_swap(a32[0], a32[1], false, false);
                                 auto b32 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
@@ -581,15 +581,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                         if (p.accumulate) {
                             if constexpr (BF) {
                                 const uint2 ov = *(const uint2*)o;
-                                v[0] += __uint_as_float(ov.x << 16); v[1] += __uint_as_float(ov.x & 0xffff0000u);
-                                v[2] += __uint_as_float(ov.y << 16); v[3] += __uint_as_float(ov.y & 0xffff0000u);
+                                float o4[4];
+                                Gran<T>::unquad(ov, o4);
+                                v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3];
                             } else {
                                 const float4 ov = *(const float4*)o;
                                 v[0] += ov.x; v[1] += ov.y; v[2] += ov.z; v[3] += ov.w;
                             }
                         }
                         if constexpr (BF) {
-                            *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                            *(uint2*)o = Gran<T>::quad(v);
                         } else {
                             *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
                         }
@@ -670,7 +671,7 @@ static bool conv_variant_fa(int dtype, int NT, int MT, int PM, int NW);
 
 static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid, int& NWsel, int pass = 0) {
     // pass 0 honours MFC_CONV_WANT_FA (fusable geometries only); if none exists the search is repeated unrestricted (pass 1)
-    bool want_fa = pass == 0 && (d->flags & MFC_CONV_WANT_FA) && d->dtype == MFC_BF16;
+    bool want_fa = pass == 0 && (d->flags & MFC_CONV_WANT_FA) && mfc_is16(d->dtype);
     if (want_fa) {
         // only where the fused epilogue's cout blocking (NT in {2, 4}) is also the natural one: for 48 / 96 / 192 / 384 channels (HRNet-W48)
         // the natural blocks are 3 or 6 tiles wide, and splitting them into blocks of 2 / 4 costs more than the fused reduce pass saves
@@ -685,8 +686,8 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
         if (ntn != 2 && ntn != 4) want_fa = false;
     }
     if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
-    if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
-    const int E = d->dtype == MFC_BF16 ? 8 : 4;
+    if (!mfc_dtype_ok(d->dtype)) return MFC_ERR_INVALID_ARG;
+    const int E = mfc_is16(d->dtype) ? 8 : 4;
     if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin > d->Cin_p || d->Cout > d->Cout_p) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->Hl <= 0 || d->Wl <= 0 || d->TA <= 0 || d->TB <= 0 || d->in_stride < 1) return MFC_ERR_INVALID_ARG;
     if ((d->Hl - 1) * d->out_sh + d->out_oh >= d->Hout || (d->Wl - 1) * d->out_sw + d->out_ow >= d->Wout) return MFC_ERR_INVALID_ARG;
@@ -783,7 +784,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     k.nunits = k.ntiles * k.Yblocks;
     k.ablate = g_conv_ablate;
     {   // cout-block-fastest order when the Yblocks passes over the input would otherwise each stream it from HBM again
-        const double in_bytes = (double)k.N * k.Hin * k.Win * k.Cin_p * (d->dtype == MFC_BF16 ? 2.0 : 4.0);
+        const double in_bytes = (double)k.N * k.Hin * k.Win * k.Cin_p * (mfc_is16(d->dtype) ? 2.0 : 4.0);
         k.ybfast = g_conv_ybfast >= 0 ? (g_conv_ybfast && k.Yblocks > 1) : (k.Yblocks > 1 && in_bytes * (k.Yblocks - 1) > 128e6);
     }
     k.wres = 0;
@@ -809,11 +810,11 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
 // with the transposed 8-channel layout, the only one that implements acc_src / bn_y; even NT so that every cout tile has a partner).
 static bool conv_variant_fa(int dtype, int NT, int MT, int PM, int NW) {
     int PMAXt = 0;
-    if (dtype == MFC_BF16 && NW == 8) PMAXt = (NT != 6 && MT == 4 && PM <= 3) ? 3 : ((MT == 2 && PM <= 4) ? 4 : ((MT == 2 && NT <= 4 && PM <= 6) ? 6 : 0));
+    if (mfc_is16(dtype) && NW == 8) PMAXt = (NT != 6 && MT == 4 && PM <= 3) ? 3 : ((MT == 2 && PM <= 4) ? 4 : ((MT == 2 && NT <= 4 && PM <= 6) ? 6 : 0));
     else if (NT == 6) PMAXt = (MT == 2 && PM <= 4) ? 4 : 0;
     else if (MT == 4) PMAXt = PM <= 3 ? 3 : ((NT <= 3 && PM <= 6) ? 6 : 0);
     else PMAXt = PM <= 4 ? 4 : 10;
-    if (!PMAXt || dtype != MFC_BF16 || (NT != 2 && NT != 4)) return false;
+    if (!PMAXt || !mfc_is16(dtype) || (NT != 2 && NT != 4)) return false;
     if (NT == 4 && MT == 2 && PMAXt == 10) return false;          // (<4,2,10,4> with the fusions compiled in spills: not offered)
     return (NT * MT <= 8) || (MT == 2 && NT <= 4 && PMAXt <= 4);
 }
@@ -867,10 +868,9 @@ extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
     return rc < 0 ? rc : (int)lds;
 }
 
-// FA instantiations with the epilogue fusions compiled in (bf16, even NT): exactly the set conv_variant_fa() accepts
-template <int NT>
+// FA instantiations with the epilogue fusions compiled in (16-bit types, even NT): exactly the set conv_variant_fa() accepts
+template <typename T, int NT>
 static int conv_dispatch_fused(const ConvK& k, int MT, int PM, int NW, size_t lds, int grid, hipStream_t st) {
-    typedef bf16_t T;
     if constexpr (NT == 2 || NT == 4) {
         if (NW == 8) {
             if constexpr (NT == 2) { if (MT == 4 && PM <= 3) return conv_launch<T, NT, 4, 3, 8, true>(k, lds, grid, st); }
@@ -932,13 +932,14 @@ extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
         if (d->bn_y && (!d->bn_coef || !d->out_stats || (d->bn_mask_mode != 0 && d->bn_mask_mode != 2 && d->bn_mask_mode != 3) ||
                         (d->bn_mask_mode == 3 && !d->bn_bits) || d->bias)) return MFC_ERR_INVALID_ARG;
         hipStream_t stf = (hipStream_t)stream;
-        if (NT == 2) return conv_dispatch_fused<2>(k, MT, PM, NW, lds, grid, stf);
-        if (NT == 4) return conv_dispatch_fused<4>(k, MT, PM, NW, lds, grid, stf);
-        return MFC_ERR_UNSUPPORTED;
+        int rcf = MFC_ERR_UNSUPPORTED;
+        if (NT == 2) MFC_TYPED16(d->dtype, T_, rcf = conv_dispatch_fused<T_, 2>(k, MT, PM, NW, lds, grid, stf));
+        else if (NT == 4) MFC_TYPED16(d->dtype, T_, rcf = conv_dispatch_fused<T_, 4>(k, MT, PM, NW, lds, grid, stf));
+        return rcf;
     }
     hipStream_t st = (hipStream_t)stream;
 #define MFC_CONV_CASE(nt) \
-    case nt: return d->dtype == MFC_BF16 ? conv_dispatch<bf16_t, nt>(k, MT, PM, NW, lds, grid, st) : conv_dispatch<float, nt>(k, MT, PM, NW, lds, grid, st);
+    case nt: { int rcd; MFC_TYPED(d->dtype, T_, rcd = conv_dispatch<T_, nt>(k, MT, PM, NW, lds, grid, st)); return rcd; }
     switch (NT) {
         MFC_CONV_CASE(1) MFC_CONV_CASE(2) MFC_CONV_CASE(3) MFC_CONV_CASE(4) MFC_CONV_CASE(6)
     }

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
                             typedef __attribute__((ext_vector_type(8))) short s16x8;
                             s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                             s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i], 0, 0, 0);
+                            acc[i] = mfma16<T>(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i]);
                         }
                     }
                 } else {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
                                 av[j] = *(const short*)(Ds + (pk + j) * p.pitch_d + oa + cl);
                                 bv[j] = *(const short*)(Xs + xoff[pk + j] + ob + cl);
                             }
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i], 0, 0, 0);
+                            acc[i] = mfma16<T>(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[i]);
                         }
                     }
                 }
@@ -285,11 +285,12 @@ struct WgradF {
     int gd, gx;                       // granules per pixel staged for dy / x
     int PW, pitch_d, pitch_x, buf_bytes, off_x, off_tab, off_coef, G;
     int slice;                        // floats per partial-sum slice of dwp
+    int f16;                          // element type: 0 bf16, 1 fp16 (host-side dispatch only)
 };
 
-template <int TB, int WCO, int WCI, bool BIG>
+template <typename TE, int TB, int WCO, int WCI, bool BIG>
 __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_fast_kernel(WgradF p) {
-    typedef bf16_t T;
+    typedef TE T;
     constexpr int WG_DP = BIG ? 6 : 3, WG_XP = BIG ? 7 : 4;
     constexpr int E = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv_wgrad_fast_kernel(Wgrad
                 for (int i = 0; i < WCO; ++i)
 #pragma unroll
                     for (int j = 0; j < WCI; ++j)
-                        acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[b][i][j], 0, 0, 0);
+                        acc[b][i][j] = mfma16<T>(af[i], bfr[j], acc[b][i][j]);
             }
         }
         if (nxt < p.ntiles) store_tile(smem + ((it + 1) & 1) * p.buf_bytes);
@@ -527,6 +528,7 @@ struct WgradW {
     int gd, gx, PW, PHX, pitch_d, pitch_x, off_x, buf_bytes, wave_bytes, off_tab, off_coef;
     int slice;       // floats per partial-sum slice of dwp
     int ablate;      // tuning only: 1 skip global loads, 2 skip LDS staging stores, 4 skip LDS reads + MFMAs, 8 skip reduction + atomics
+    int f16;         // element type: 0 bf16, 1 fp16 (host-side dispatch only)
 };
 
 // Up to 8 weight gradients of IDENTICAL geometry share one launch (mfc_conv2d_wgrad_batch): the workgroups are dealt to the
@@ -538,9 +540,9 @@ struct WgradBatch {
     const float* coef[MFC_WGRAD_MAXBATCH]; int relu[MFC_WGRAD_MAXBATCH]; int n;
 };
 
-template <int TAA, int TB, int WCO, int WCI, int XP, int PF>
+template <typename TE, int TAA, int TB, int WCO, int WCI, int XP, int PF>
 __global__ __launch_bounds__(256, PF == 2 ? 1 : 2) void conv_wgrad_wave_kernel(WgradW p, WgradBatch tb) {
-    typedef bf16_t T;
+    typedef TE T;
     constexpr int E = 8;
     constexpr int DP = 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(256, PF == 2 ? 1 : 2) void conv_wgrad_wave_kernel(W
             for (int i = 0; i < WCO; ++i)
 #pragma unroll
                 for (int j = 0; j < WCI; ++j)
-                    acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[b][i][j], 0, 0, 0);
+                    acc[b][i][j] = mfma16<T>(af[i], bfr[j], acc[b][i][j]);
         }
     };
     if constexpr (PF == 1) {
@@ -857,16 +859,19 @@ template <int TB, int WCO, int WCI, bool BIG>
 static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_fast_kernel<bf16_t, TB, WCO, WCI, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_fast_kernel<f16_t, TB, WCO, WCI, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB;
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0;
-        MFC_PROF_NAME(pname, "conv_wgrad_fast_kernel<%d, %d, %d, %s>", TB, WCO, WCI, BIG ? "true" : "false");
-        mfc_prof_before(st, pname, flops, bytes);
+        MFC_PROF_NAME(pname, "conv_wgrad_fast_kernel<__bf16, %d, %d, %d, %s>", TB, WCO, WCI, BIG ? "true" : "false");
+        MFC_PROF_NAME(hname, "conv_wgrad_fast_kernel<_Float16, %d, %d, %d, %s>", TB, WCO, WCI, BIG ? "true" : "false");
+        mfc_prof_before(st, f.f16 ? hname : pname, flops, bytes);
     }
-    hipLaunchKernelGGL((conv_wgrad_fast_kernel<TB, WCO, WCI, BIG>), dim3(f.splits * Y), dim3(256), lds, st, f);
+    if (f.f16) hipLaunchKernelGGL((conv_wgrad_fast_kernel<f16_t, TB, WCO, WCI, BIG>), dim3(f.splits * Y), dim3(256), lds, st, f);
+    else hipLaunchKernelGGL((conv_wgrad_fast_kernel<bf16_t, TB, WCO, WCI, BIG>), dim3(f.splits * Y), dim3(256), lds, st, f);
     if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -874,9 +879,10 @@ static int wgrad_fast_launch(const WgradF& f, size_t lds, int Y, hipStream_t st)
 
 // returns MFC_ERR_UNSUPPORTED when the geometry does not fit the fast kernel (caller falls back)
 static int wgrad_fast(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only) {
-    if (d->dtype != MFC_BF16 || !g_wgrad_use_tr) return MFC_ERR_UNSUPPORTED;
+    if (!mfc_is16(d->dtype) || !g_wgrad_use_tr) return MFC_ERR_UNSUPPORTED;
     if (d->TB != 1 && d->TB != 3 && d->TB != 11) return MFC_ERR_UNSUPPORTED;
     WgradF f;
+    f.f16 = d->dtype == MFC_F16;
     f.x = (const char*)d->x; f.dy = (const char*)d->dy; f.dwp = d->dwp; f.in_coef = d->in_coef;
     f.N = d->N; f.Hin = d->Hin; f.Win = d->Win; f.Cin_p = d->Cin_p; f.Hout = d->Hout; f.Wout = d->Wout; f.Cout_p = d->Cout_p;
     f.TA = d->TA; f.TB = d->TB; f.dh0 = d->dh0; f.dw0 = d->dw0; f.s = d->in_stride; f.in_relu = d->in_relu; f.ipg = d->images_per_group;
@@ -940,16 +946,19 @@ template <int TAA, int TB, int WCO, int WCI, int XP, int PF>
 static int wgrad_wave_launch(const WgradW& f, const WgradBatch& tb, size_t lds, int Y, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<bf16_t, TAA, TB, WCO, WCI, XP, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wave_kernel<f16_t, TAA, TB, WCO, WCI, XP, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * f.N * f.Hout * f.Wout * (double)f.Co16 * f.Ci16 * f.TA * f.TB * tb.n;
         const double bytes = ((double)f.N * f.Hin * f.Win * f.Cin_p + (double)f.N * f.Hout * f.Wout * f.Cout_p) * 2.0 * tb.n;
-        MFC_PROF_NAME(pname, "conv_wgrad_wave_kernel<%d, %d, %d, %d, %d, %d>", TAA, TB, WCO, WCI, XP, PF);
-        mfc_prof_before(st, pname, flops, bytes);
+        MFC_PROF_NAME(pname, "conv_wgrad_wave_kernel<__bf16, %d, %d, %d, %d, %d, %d>", TAA, TB, WCO, WCI, XP, PF);
+        MFC_PROF_NAME(hname, "conv_wgrad_wave_kernel<_Float16, %d, %d, %d, %d, %d, %d>", TAA, TB, WCO, WCI, XP, PF);
+        mfc_prof_before(st, f.f16 ? hname : pname, flops, bytes);
     }
-    hipLaunchKernelGGL((conv_wgrad_wave_kernel<TAA, TB, WCO, WCI, XP, PF>), dim3(f.splits * Y * tb.n), dim3(256), lds, st, f, tb);
+    if (f.f16) hipLaunchKernelGGL((conv_wgrad_wave_kernel<f16_t, TAA, TB, WCO, WCI, XP, PF>), dim3(f.splits * Y * tb.n), dim3(256), lds, st, f, tb);
+    else hipLaunchKernelGGL((conv_wgrad_wave_kernel<bf16_t, TAA, TB, WCO, WCI, XP, PF>), dim3(f.splits * Y * tb.n), dim3(256), lds, st, f, tb);
     if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -970,9 +979,10 @@ static void choose_subtile(int Hl, int Wl, int& TH, int& TW, int max_patch = 0) 
 }
 
 static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only, const mfc_wgrad_desc* batch = nullptr, int nbatch = 1) {
-    if (d->dtype != MFC_BF16 || !g_wgrad_use_tr || g_wgrad_ksplit == 2) return MFC_ERR_UNSUPPORTED;
+    if (!mfc_is16(d->dtype) || !g_wgrad_use_tr || g_wgrad_ksplit == 2) return MFC_ERR_UNSUPPORTED;
     if (d->TB != 3 && d->TB != 11) return MFC_ERR_UNSUPPORTED;
     WgradW f;
+    f.f16 = d->dtype == MFC_F16;
     f.x = (const char*)d->x; f.dy = (const char*)d->dy; f.dwp = d->dwp; f.in_coef = d->in_coef;
     f.N = d->N; f.Hin = d->Hin; f.Win = d->Win; f.Cin_p = d->Cin_p; f.Hout = d->Hout; f.Wout = d->Wout; f.Cout_p = d->Cout_p;
     f.TA = d->TA; f.TB = d->TB; f.dh0 = d->dh0; f.dw0 = d->dw0; f.s = d->in_stride; f.in_relu = d->in_relu; f.ipg = d->images_per_group;
@@ -1077,7 +1087,7 @@ int wgrad_gemm1x1_launch(const mfc_wgrad_desc* d, hipStream_t st);
 
 static int wgrad_any(const mfc_wgrad_desc* d, void* stream, int* parts_only) {
     if (!d || !d->x || !d->dy || !d->dwp) return MFC_ERR_INVALID_ARG;
-    if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
+    if (!mfc_dtype_ok(d->dtype)) return MFC_ERR_INVALID_ARG;
     if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin > d->Cin_p || d->Cout > d->Cout_p) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->TA <= 0 || d->TB <= 0 || d->in_stride < 1 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
     if (wgrad_gemm1x1_eligible(d)) {
@@ -1095,7 +1105,7 @@ static int wgrad_any(const mfc_wgrad_desc* d, void* stream, int* parts_only) {
         rcf = wgrad_fast(d, (hipStream_t)stream, parts_only);
         if (rcf != MFC_ERR_UNSUPPORTED) return rcf;
     }
-    const int esz = d->dtype == MFC_BF16 ? 2 : 4;
+    const int esz = mfc_is16(d->dtype) ? 2 : 4;
     WgradK k;
     k.x = (const char*)d->x; k.dy = (const char*)d->dy; k.dwp = d->dwp; k.in_coef = d->in_coef;
     k.N = d->N; k.Hin = d->Hin; k.Win = d->Win; k.Cin_p = d->Cin_p; k.Hout = d->Hout; k.Wout = d->Wout; k.Cout_p = d->Cout_p;
@@ -1132,15 +1142,18 @@ static int wgrad_any(const mfc_wgrad_desc* d, void* stream, int* parts_only) {
     if (parts_only) { *parts_only = S; return MFC_OK; }
     hipStream_t st = (hipStream_t)stream;
     const bool tr = g_wgrad_use_tr != 0;
-    if (d->dtype == MFC_BF16) {
+    if (mfc_is16(d->dtype)) {
+        int rcw;
         if (tr) {
-            if (TPW == 8) return wgrad_launch<bf16_t, 8, true>(k, lds, Y, st);
-            if (TPW == 16) return wgrad_launch<bf16_t, 16, true>(k, lds, Y, st);
-            return wgrad_launch<bf16_t, 28, true>(k, lds, Y, st);
+            if (TPW == 8) MFC_TYPED16(d->dtype, T_, rcw = wgrad_launch<T_, 8, true>(k, lds, Y, st));
+            else if (TPW == 16) MFC_TYPED16(d->dtype, T_, rcw = wgrad_launch<T_, 16, true>(k, lds, Y, st));
+            else MFC_TYPED16(d->dtype, T_, rcw = wgrad_launch<T_, 28, true>(k, lds, Y, st));
+            return rcw;
         }
-        if (TPW == 8) return wgrad_launch<bf16_t, 8, false>(k, lds, Y, st);
-        if (TPW == 16) return wgrad_launch<bf16_t, 16, false>(k, lds, Y, st);
-        return wgrad_launch<bf16_t, 28, false>(k, lds, Y, st);
+        if (TPW == 8) MFC_TYPED16(d->dtype, T_, rcw = wgrad_launch<T_, 8, false>(k, lds, Y, st));
+        else if (TPW == 16) MFC_TYPED16(d->dtype, T_, rcw = wgrad_launch<T_, 16, false>(k, lds, Y, st));
+        else MFC_TYPED16(d->dtype, T_, rcw = wgrad_launch<T_, 28, false>(k, lds, Y, st));
+        return rcw;
     }
     if (TPW == 8) return wgrad_launch<float, 8, false>(k, lds, Y, st);
     if (TPW == 16) return wgrad_launch<float, 16, false>(k, lds, Y, st);
@@ -1175,7 +1188,7 @@ extern "C" int mfc_conv2d_wgrad_batch(const mfc_wgrad_desc* descs, int32_t n, vo
             b.splits != a.splits)
             return MFC_ERR_INVALID_ARG;
     }
-    if (a.dtype != MFC_BF16) return MFC_ERR_UNSUPPORTED;
+    if (!mfc_is16(a.dtype)) return MFC_ERR_UNSUPPORTED;
     if (a.Cin_p % 8 || a.Cout_p % 8 || a.Cin > a.Cin_p || a.Cout > a.Cout_p || a.N <= 0 || a.images_per_group <= 0 || a.N % a.images_per_group) return MFC_ERR_INVALID_ARG;
     return wgrad_wave(&a, (hipStream_t)stream, nullptr, descs, n);
 }

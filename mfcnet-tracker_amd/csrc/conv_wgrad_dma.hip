@@ -45,9 +45,9 @@ __device__ inline void wd_dma(const char* base, unsigned voff, unsigned lds) {
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds) : "memory");
 }
 
-template <bool XF>
+template <typename TE, bool XF>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(WgradD p) {
-    typedef bf16_t T;
+    typedef TE T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(WgradD p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[b][i][j], 0, 0, 0);
+                    acc[b][i][j] = mfma16<T>(af[i], bfr[j], acc[b][i][j]);
         }
     };
 
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(WgradD p) {
 }
 
 bool wgrad_dma_eligible(const mfc_wgrad_desc* d) {
-    if (!g_wgrad_dma || d->dtype != MFC_BF16 || d->batch > 1) return false;
+    if (!g_wgrad_dma || !mfc_is16(d->dtype) || d->batch > 1) return false;
     if (d->TA != 3 || d->TB != 3 || d->in_stride != 1 || d->dh0 != -1 || d->dw0 != -1) return false;
     if (d->Hin != d->Hout || d->Win != d->Wout) return false;
     if (d->Cin % 32 || d->Cout % 32 || d->Cin_p != d->Cin || d->Cout_p != d->Cout) return false;      // whole 32-channel blocks
@@ -320,18 +320,22 @@ int wgrad_dma_launch(const mfc_wgrad_desc* d, hipStream_t st) {
     const size_t lds = (size_t)4 * WD_WAVE + (xf ? (size_t)f.G * 64 * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * f.N * f.H * f.W * (double)f.Co16 * f.Ci16 * 9.0;
         const double bytes = ((double)f.N * f.H * f.W * (f.Cin_p + f.Cout_p)) * 2.0;
-        mfc_prof_before(st, xf ? "conv_wgrad_dma_kernel<true>" : "conv_wgrad_dma_kernel<false>", flops, bytes);
+        const bool h = d->dtype == MFC_F16;
+        mfc_prof_before(st, h ? (xf ? "conv_wgrad_dma_kernel<_Float16, true>" : "conv_wgrad_dma_kernel<_Float16, false>")
+                              : (xf ? "conv_wgrad_dma_kernel<__bf16, true>" : "conv_wgrad_dma_kernel<__bf16, false>"), flops, bytes);
     }
     const int grid = f.splits * f.co_blocks * f.ci_blocks;
-    if (xf) hipLaunchKernelGGL(conv_wgrad_dma_kernel<true>, dim3(grid), dim3(256), lds, st, f);
-    else hipLaunchKernelGGL(conv_wgrad_dma_kernel<false>, dim3(grid), dim3(256), lds, st, f);
+    if (xf) MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, true>), dim3(grid), dim3(256), lds, st, f));
+    else MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, false>), dim3(grid), dim3(256), lds, st, f));
     if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;

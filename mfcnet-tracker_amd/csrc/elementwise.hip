@@ -11,7 +11,7 @@
 
 // event-profiler bracket of an element-wise launch: the row is named like the kernel rocprofv3 reports; BYTES = the tensors the launch
 // must touch once (its algorithmic HBM traffic)
-#define EW_PROF(st, KERNEL, DTYPE, BYTES) do { if (g_mfc_prof_on == 1) mfc_prof_before(st, (DTYPE) == MFC_BF16 ? KERNEL "<__bf16>" : KERNEL "<float>", 0.0, (double)(BYTES)); } while (0)
+#define EW_PROF(st, KERNEL, DTYPE, BYTES) do { if (g_mfc_prof_on == 1) mfc_prof_before(st, (DTYPE) == MFC_BF16 ? KERNEL "<__bf16>" : ((DTYPE) == MFC_F16 ? KERNEL "<_Float16>" : KERNEL "<float>"), 0.0, (double)(BYTES)); } while (0)
 static inline double view_bytes(const mfc_view& v, int N, int C, int esz) { return v.ptr ? (double)N * v.H * v.W * C * esz : 0.0; }
 
 // ------------------------------------------------------------------ BN finalize
@@ -231,8 +231,8 @@ static bool view_ok(const mfc_view& v, int E) { return v.ptr && v.H > 0 && v.W >
 
 extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
     if (!d || d->nsrc < 1 || d->nsrc > 4) return MFC_ERR_INVALID_ARG;
-    const int E = d->dtype == MFC_BF16 ? 8 : 4;
-    if (d->dtype != MFC_F32 && d->dtype != MFC_BF16) return MFC_ERR_INVALID_ARG;
+    const int E = mfc_is16(d->dtype) ? 8 : 4;
+    if (!mfc_dtype_ok(d->dtype)) return MFC_ERR_INVALID_ARG;
     if (!view_ok(d->out, E) || d->C <= 0 || d->C % E || d->N <= 0 || d->images_per_group <= 0) return MFC_ERR_INVALID_ARG;
     if (d->out.c_off + d->C > d->out.Cp) return MFC_ERR_INVALID_ARG;
     for (int k = 0; k < d->nsrc; ++k)
@@ -249,15 +249,13 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
     if (same) {
         const int b2 = (int)((total + 511) / 512);
         EW_PROF(st, "combine_same_kernel", d->dtype, cbytes);
-        if (d->dtype == MFC_BF16) hipLaunchKernelGGL(combine_same_kernel<bf16_t>, dim3(b2), dim3(256), 0, st, *d, total, Cg);
-        else hipLaunchKernelGGL(combine_same_kernel<float>, dim3(b2), dim3(256), 0, st, *d, total, Cg);
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(combine_same_kernel<T_>, dim3(b2), dim3(256), 0, st, *d, total, Cg));
         MFC_PROF_END(st);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
     }
     EW_PROF(st, "combine_fwd_kernel", d->dtype, cbytes);
-    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(combine_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
-    else hipLaunchKernelGGL(combine_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(combine_fwd_kernel<T_>, dim3(blocks), dim3(256), 0, st, *d, total, Cg));
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -363,13 +361,13 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
 
 int g_bnred_blocks = 1024;           // workgroups of a BN-backward reduce launch; tuning: mfc_set_flag(27, n)
 static int bnbwd_check(const mfc_bnbwd_desc* d, int& E) {
-    if (!d || (d->dtype != MFC_F32 && d->dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
-    E = d->dtype == MFC_BF16 ? 8 : 4;
+    if (!d || (!mfc_dtype_ok(d->dtype))) return MFC_ERR_INVALID_ARG;
+    E = mfc_is16(d->dtype) ? 8 : 4;
     if (!view_ok(d->g, E) || !view_ok(d->y, E) || !d->y.coef || d->C <= 0 || d->C % E) return MFC_ERR_INVALID_ARG;
     if (d->g.H != d->y.H || d->g.W != d->y.W) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode == 1 && (!view_ok(d->mask, E) || d->mask.H != d->y.H || d->mask.W != d->y.W)) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode < 0 || d->mask_mode > 3) return MFC_ERR_INVALID_ARG;
-    if (d->mask_mode == 3 && (d->dtype != MFC_BF16 || !d->mask.ptr || d->mask.Cp % 8 || d->mask.c_off % 8 || d->mask.H != d->y.H || d->mask.W != d->y.W)) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode == 3 && (!mfc_is16(d->dtype) || !d->mask.ptr || d->mask.Cp % 8 || d->mask.c_off % 8 || d->mask.H != d->y.H || d->mask.W != d->y.W)) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
     return MFC_OK;
 }
@@ -393,8 +391,7 @@ extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
         const double t = (double)d->N * d->y.H * d->y.W * d->C * esz;         // one tensor
         EW_PROF(st, "bnbwd_reduce_kernel", d->dtype, t * (2 + (d->mask_mode == 1 ? 1 : 0) + (d->dy.ptr ? (d->accumulate ? 2 : 1) : 0)) + (d->mask_mode == 3 ? t / 16 : 0));
     }
-    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_reduce_kernel<bf16_t>, dim3(bx, G), dim3(Cg * PPI), 0, st, *d, Cg, PPI, ppb, ppg);
-    else hipLaunchKernelGGL(bnbwd_reduce_kernel<float>, dim3(bx, G), dim3(Cg * PPI), 0, st, *d, Cg, PPI, ppb, ppg);
+    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_reduce_kernel<T_>, dim3(bx, G), dim3(Cg * PPI), 0, st, *d, Cg, PPI, ppb, ppg));
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -546,8 +543,7 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
         const int grid = nchunks < 1024u ? (int)nchunks : 1024;
         hipStream_t s2 = (hipStream_t)stream;
         EW_PROF(s2, "bnbwd_apply_fin_kernel", d->dtype, (double)tot * 16.0 * (3 + (d->mask_mode == 1 ? 1 : 0)) + (d->mask_mode == 3 ? (double)tot : 0.0));
-        if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_apply_fin_kernel<bf16_t>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, nchunks);
-        else hipLaunchKernelGGL(bnbwd_apply_fin_kernel<float>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, nchunks);
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_apply_fin_kernel<T_>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, nchunks));
         MFC_PROF_END(s2);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
@@ -559,8 +555,7 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
     const int blocks = (int)((total + 1023) / 1024);
     hipStream_t st = (hipStream_t)stream;
     EW_PROF(st, "bnbwd_apply_kernel", d->dtype, (double)total * 16.0 * (3 + (d->mask_mode == 1 ? 1 : 0)) + (d->mask_mode == 3 ? (double)total : 0.0));
-    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(bnbwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
-    else hipLaunchKernelGGL(bnbwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total, Cg);
+    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_apply_kernel<T_>, dim3(blocks), dim3(256), 0, st, *d, total, Cg));
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -789,12 +784,12 @@ __global__ __launch_bounds__(256) void mask_add_same_kernel(mfc_maskadd_desc d, 
 }
 
 extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
-    if (!d || (d->dtype != MFC_F32 && d->dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
-    const int E = d->dtype == MFC_BF16 ? 8 : 4;
+    if (!d || (!mfc_dtype_ok(d->dtype))) return MFC_ERR_INVALID_ARG;
+    const int E = mfc_is16(d->dtype) ? 8 : 4;
     if (!view_ok(d->g, E) || !view_ok(d->dst, E) || d->C <= 0 || d->C % E || d->N <= 0) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode != 0 && d->mask_mode != 1 && d->mask_mode != 3) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode == 1 && (!view_ok(d->mask, E) || d->mask.H != d->g.H || d->mask.W != d->g.W)) return MFC_ERR_INVALID_ARG;
-    if (d->mask_mode == 3 && (d->dtype != MFC_BF16 || !d->mask.ptr || d->mask.Cp % 8 || d->mask.c_off % 8 || d->mask.H != d->g.H || d->mask.W != d->g.W)) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode == 3 && (!mfc_is16(d->dtype) || !d->mask.ptr || d->mask.Cp % 8 || d->mask.c_off % 8 || d->mask.H != d->g.H || d->mask.W != d->g.W)) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     const long total = (long)d->N * d->dst.H * d->dst.W * Cg;
     if (total >= (1L << 31) - 2048 || (long)d->N * d->g.H * d->g.W * Cg >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;
@@ -803,8 +798,7 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
     if (d->dst.H == d->g.H && d->dst.W == d->g.W) {
         const int b4 = (int)((total + 1023) / 1024);
         EW_PROF(st, "mask_add_same_kernel", d->dtype, (double)total * 16.0 * (2 + (d->mask_mode == 1 ? 1 : 0) + (d->accumulate ? 1 : 0)) + (d->mask_mode == 3 ? (double)total : 0.0));
-        if (d->dtype == MFC_BF16) hipLaunchKernelGGL(mask_add_same_kernel<bf16_t>, dim3(b4), dim3(256), 0, st, *d, total, Cg);
-        else hipLaunchKernelGGL(mask_add_same_kernel<float>, dim3(b4), dim3(256), 0, st, *d, total, Cg);
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(mask_add_same_kernel<T_>, dim3(b4), dim3(256), 0, st, *d, total, Cg));
         MFC_PROF_END(st);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
@@ -817,13 +811,8 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
         // (both passes in one row: the pair is one up-sampling adjoint; bytes = the high-resolution gradient (+ mask) read once + the result)
         const double hi = (double)d->N * d->g.H * d->g.W * Cg * 16.0;
         EW_PROF(st, "mask_add_wpass+hpass_kernel", d->dtype, hi * (1 + (d->mask_mode == 1 ? 1 : 0)) + (d->mask_mode == 3 ? hi / 16 : 0) + (double)total * 16.0 * (d->accumulate ? 2 : 1));
-        if (d->dtype == MFC_BF16) {
-            hipLaunchKernelGGL(mask_add_wpass_kernel<bf16_t>, dim3(b1), dim3(256), 0, st, *d, (unsigned)t1, Cg);
-            hipLaunchKernelGGL(mask_add_hpass_kernel<bf16_t>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg);
-        } else {
-            hipLaunchKernelGGL(mask_add_wpass_kernel<float>, dim3(b1), dim3(256), 0, st, *d, (unsigned)t1, Cg);
-            hipLaunchKernelGGL(mask_add_hpass_kernel<float>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg);
-        }
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(mask_add_wpass_kernel<T_>, dim3(b1), dim3(256), 0, st, *d, (unsigned)t1, Cg);
+                  hipLaunchKernelGGL(mask_add_hpass_kernel<T_>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg));
         MFC_PROF_END(st);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
@@ -836,8 +825,7 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
     const long npo = (long)d->N * d->dst.H * d->dst.W;
     const int blocksS = (int)((npo + PB - 1) / PB);
     (void)blocks;
-    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(mask_add_kernel<bf16_t>, dim3(blocksS), dim3(256), 0, st, *d, npo, Cg, LS, PB);
-    else hipLaunchKernelGGL(mask_add_kernel<float>, dim3(blocksS), dim3(256), 0, st, *d, npo, Cg, LS, PB);
+    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(mask_add_kernel<T_>, dim3(blocksS), dim3(256), 0, st, *d, npo, Cg, LS, PB));
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -890,9 +878,9 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* dy, float* db, 
 
 extern "C" int mfc_bias_grad(const void* dy, float* db, int32_t dtype, int64_t npix, int32_t Cp, int32_t C, void* stream) {
     if (!dy || !db || npix <= 0 || Cp <= 0 || C > Cp || Cp % 8) return MFC_ERR_INVALID_ARG;
-    if (dtype != MFC_BF16 && dtype != MFC_F32) return MFC_ERR_INVALID_ARG;
+    if (!mfc_dtype_ok(dtype)) return MFC_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int E = dtype == MFC_BF16 ? 8 : 4;
+    const int E = mfc_is16(dtype) ? 8 : 4;
     const int Cgt = Cp / E;                                // granules per pixel
     // channel slabs of <= 16 granules: many pixel rows per workgroup, so few workgroups (= few same-address atomics) suffice
     const int nslab = (Cgt + 15) / 16;
@@ -903,8 +891,7 @@ extern "C" int mfc_bias_grad(const void* dy, float* db, int32_t dtype, int64_t n
     ppb = ((ppb + PPI - 1) / PPI) * PPI;
     const int blocks = (int)((npix + ppb - 1) / ppb);
     EW_PROF(st, "bias_grad_kernel", dtype, (double)npix * Cp * (E == 8 ? 2 : 4));
-    if (dtype == MFC_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(blocks, nslab), dim3(Cg * PPI), 0, st, (const bf16_t*)dy, db, (long)npix, Cp, C, Cg, PPI, ppb);
-    else hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks, nslab), dim3(Cg * PPI), 0, st, (const float*)dy, db, (long)npix, Cp, C, Cg, PPI, ppb);
+    MFC_TYPED(dtype, T_, hipLaunchKernelGGL(bias_grad_kernel<T_>, dim3(blocks, nslab), dim3(Cg * PPI), 0, st, (const T_*)dy, db, (long)npix, Cp, C, Cg, PPI, ppb));
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -933,15 +920,13 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* 
 extern "C" int mfc_nchw_to_nhwc(const float* src, void* dst, int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W,
                                 int32_t Cp, int32_t c_off, int32_t zero_pad, void* stream) {
     (void)zero_pad;
-    if (!src || !dst || N <= 0 || C <= 0 || Cp % 8) return MFC_ERR_INVALID_ARG;
-    const int E = dtype == MFC_BF16 ? 8 : 4;
+    if (!src || !dst || N <= 0 || C <= 0 || Cp % 8 || !mfc_dtype_ok(dtype)) return MFC_ERR_INVALID_ARG;
+    const int E = mfc_is16(dtype) ? 8 : 4;
     if (c_off % E || c_off + ((C + E - 1) / E) * E > Cp) return MFC_ERR_INVALID_ARG;
     const long total = (long)N * H * W;
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, src, (bf16_t*)dst, N, C, H, W, Cp, c_off, total);
-    else if (dtype == MFC_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, N, C, H, W, Cp, c_off, total);
-    else return MFC_ERR_INVALID_ARG;
+    MFC_TYPED(dtype, T_, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T_>, dim3(blocks), dim3(256), 0, st, src, (T_*)dst, N, C, H, W, Cp, c_off, total));
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -957,13 +942,11 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* src, float* 
 
 extern "C" int mfc_nhwc_to_nchw(const void* src, float* dst, int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W,
                                 int32_t Cp, void* stream) {
-    if (!src || !dst || N <= 0 || C <= 0 || C > Cp) return MFC_ERR_INVALID_ARG;
+    if (!src || !dst || N <= 0 || C <= 0 || C > Cp || !mfc_dtype_ok(dtype)) return MFC_ERR_INVALID_ARG;
     const long HW = (long)H * W, total = (long)N * C * HW;
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, C, HW, Cp, total);
-    else if (dtype == MFC_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, dst, C, HW, Cp, total);
-    else return MFC_ERR_INVALID_ARG;
+    MFC_TYPED(dtype, T_, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T_>, dim3(blocks), dim3(256), 0, st, (const T_*)src, dst, C, HW, Cp, total));
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }
@@ -1056,7 +1039,7 @@ __global__ __launch_bounds__(256) void head_gather_fwd_kernel(mfc_headgather_des
 }
 
 static int head_check(const mfc_headgather_desc* d) {
-    if (!d || !d->logits || !d->xh || (d->dtype != MFC_F32 && d->dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
+    if (!d || !d->logits || !d->xh || (!mfc_dtype_ok(d->dtype))) return MFC_ERR_INVALID_ARG;
     if (d->T < 1 || d->T > 8 || d->nc < 1 || d->nc > d->Lp || d->Cp % 8 || d->Cp > 40 || d->Lp % 8) return MFC_ERR_INVALID_ARG;
     int c = d->T * d->nc + ((!d->warp && d->flow[0]) ? 2 * (d->T - 1) : 0) + (d->depth[0] ? d->T : 0);
     if (c > d->Cp) return MFC_ERR_INVALID_ARG;
@@ -1070,11 +1053,10 @@ extern "C" int mfc_head_gather_fwd(const mfc_headgather_desc* d, void* stream) {
     const long total = (long)d->B * d->H * d->W;
     const int blocks = (int)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-    const int hesz = d->dtype == MFC_BF16 ? 2 : 4;
+    const int hesz = mfc_is16(d->dtype) ? 2 : 4;
     EW_PROF(st, "head_gather_fwd_kernel", d->dtype, (double)total * d->Cp * hesz + (double)d->T * d->B * d->Hs * d->Ws * d->Lp * hesz
             + (double)total * 4.0 * ((d->flow[0] ? 2 * (d->T - 1) : 0) + (d->depth[0] ? d->T : 0)));
-    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, total);
-    else hipLaunchKernelGGL(head_gather_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, total);
+    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(head_gather_fwd_kernel<T_>, dim3(blocks), dim3(256), 0, st, *d, total));
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -1206,15 +1188,13 @@ extern "C" int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, 
         if (hipMemsetAsync(dU, 0, bytes, st) != hipSuccess) return MFC_ERR_LAUNCH;
         const long tot = (long)d->B * d->H * d->W;
         const int blk = (int)((tot + 255) / 256);
-        if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_warp_scatter_kernel<bf16_t>, dim3(blk), dim3(256), 0, st, *d, dU, tot);
-        else hipLaunchKernelGGL(head_warp_scatter_kernel<float>, dim3(blk), dim3(256), 0, st, *d, dU, tot);
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(head_warp_scatter_kernel<T_>, dim3(blk), dim3(256), 0, st, *d, dU, tot));
     }
     const long total = (long)d->B * d->Hs * d->Ws;
     const int blocks = (int)((total + 255) / 256);
-    const int hesz = d->dtype == MFC_BF16 ? 2 : 4;
+    const int hesz = mfc_is16(d->dtype) ? 2 : 4;
     EW_PROF(st, "head_gather_bwd_kernel", d->dtype, (double)d->B * d->H * d->W * d->Cp * hesz + (double)d->T * total * d->Lp * hesz);
-    if (d->dtype == MFC_BF16) hipLaunchKernelGGL(head_gather_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, *d, (bf16_t*)dlogits, (const float*)dU, total);
-    else hipLaunchKernelGGL(head_gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, *d, (float*)dlogits, (const float*)dU, total);
+    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(head_gather_bwd_kernel<T_>, dim3(blocks), dim3(256), 0, st, *d, (T_*)dlogits, (const float*)dU, total));
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -1294,8 +1274,8 @@ __global__ __launch_bounds__(256) void upsample_nearest2x_kernel(const char* src
     *(uint4*)(dst + idx * 16) = *(const uint4*)(src + ((((size_t)n * H + (h >> 1)) * W + (w >> 1)) * Cg + g) * 16);
 }
 extern "C" int mfc_upsample_nearest2x(const void* src, void* dst, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t Cp, void* stream) {
-    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || Cp <= 0 || Cp % 8 || (dtype != MFC_F32 && dtype != MFC_BF16)) return MFC_ERR_INVALID_ARG;
-    const int Cg = Cp / (dtype == MFC_BF16 ? 8 : 4);
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || Cp <= 0 || Cp % 8 || (!mfc_dtype_ok(dtype))) return MFC_ERR_INVALID_ARG;
+    const int Cg = Cp / (mfc_is16(dtype) ? 8 : 4);
     const long total = (long)N * 2 * H * 2 * W * Cg;
     hipLaunchKernelGGL(upsample_nearest2x_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const char*)src, (char*)dst, H, W, Cg, total);

@@ -42,11 +42,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const mfc_pack_job* j
 }
 
 extern "C" int mfc_pack_weights(const mfc_pack_job* jobs_dev, int32_t njobs, int32_t total_blocks, int32_t dtype, void* stream) {
-    if (!jobs_dev || njobs <= 0 || total_blocks <= 0) return MFC_ERR_INVALID_ARG;
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0 || !mfc_dtype_ok(dtype)) return MFC_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFC_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs);
-    else if (dtype == MFC_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs);
-    else return MFC_ERR_INVALID_ARG;
+    MFC_TYPED(dtype, T_, hipLaunchKernelGGL(pack_weights_kernel<T_>, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs));
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

@@ -28,6 +28,7 @@ constexpr int WG_OFF_D0 = 0, WG_OFF_D1 = WG_TILE, WG_OFF_X0 = 2 * WG_TILE, WG_OF
 constexpr int WG_OFF_COEF = 4 * WG_TILE;                         // float [G <= 8][2][256]: scale / shift of the block's input channels
 constexpr int WG_LDS = 4 * WG_TILE + 8 * 2 * WG_C * 4;
 
+template <typename TE>
 __global__ __launch_bounds__(512, 1) void wgrad_gemm1x1_kernel(WgG p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) s16x4 lds_s4;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm1x1_kernel(WgG p) {
             const int pp = idx >> 5, g = (idx & 31) ^ (2 * (pp & 15));
             uint4 v = *(const uint4*)(X + idx * 16);
             float f[8];
-            Gran<bf16_t>::unpack(v, f);
+            Gran<TE>::unpack(v, f);
             const float4 s0 = *(const float4*)(sc + g * 8), s1 = *(const float4*)(sc + g * 8 + 4);
             const float4 h0 = *(const float4*)(sc + WG_C + g * 8), h1 = *(const float4*)(sc + WG_C + g * 8 + 4);
             const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm1x1_kernel(WgG p) {
                 const float t = f[e] * scv[e] + shv[e];
                 f[e] = p.in_relu ? relu_nan(t) : t;
             }
-            *(uint4*)(X + idx * 16) = Gran<bf16_t>::pack(f);
+            *(uint4*)(X + idx * 16) = Gran<TE>::pack(f);
         }
     };
 
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm1x1_kernel(WgG p) {
                     if (j < njv) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            if (i < niv) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                            if (i < niv) acc[i][j] = mfma16<TE>(af[i], bfr[j], acc[i][j]);
                     }
             }
         }
@@ -177,7 +178,7 @@ int g_wgrad_gemm_minc = 64;          // smallest Cin / Cout sent there; tuning: 
 int g_wgrad_gemm = 1;                // big 1x1 weight gradients through wgrad_gemm1x1_kernel; tuning: mfc_set_flag(25, v)
 
 bool wgrad_gemm1x1_eligible(const mfc_wgrad_desc* d) {
-    if (!g_wgrad_gemm || d->dtype != MFC_BF16) return false;
+    if (!g_wgrad_gemm || !mfc_is16(d->dtype)) return false;
     if (d->TA != 1 || d->TB != 1 || d->in_stride != 1 || d->dh0 != 0 || d->dw0 != 0) return false;
     if (d->Hin != d->Hout || d->Win != d->Wout || d->batch > 1) return false;
     if (d->in_coef) {      // a 64-pixel stage never straddles a statistics group
@@ -212,15 +213,16 @@ int wgrad_gemm1x1_launch(const mfc_wgrad_desc* d, hipStream_t st) {
     WgG k; wgrad_gemm1x1_setup(d, k);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_gemm1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_gemm1x1_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_gemm1x1_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * k.M * (double)k.Co16 * k.Ci16;
         const double bytes = (double)k.M * (k.Cin_p + k.Cout_p) * 2.0;
-        mfc_prof_before(st, "wgrad_gemm1x1_kernel", flops, bytes);
+        mfc_prof_before(st, d->dtype == MFC_F16 ? "wgrad_gemm1x1_kernel<_Float16>" : "wgrad_gemm1x1_kernel<__bf16>", flops, bytes);
     }
-    hipLaunchKernelGGL(wgrad_gemm1x1_kernel, dim3(k.co_blocks * k.ci_blocks * k.S), dim3(512), WG_LDS, st, k);
+    MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL(wgrad_gemm1x1_kernel<T_>, dim3(k.co_blocks * k.ci_blocks * k.S), dim3(512), WG_LDS, st, k));
     if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;

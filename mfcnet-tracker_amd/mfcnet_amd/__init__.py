@@ -3,7 +3,7 @@
 Drop-in for the reference's `models.get_multiframe_segmentation_model` on the
 `HRNetMulti-Large` / `HRNetMulti-Basic` model types (models/__init__.py:79-84).
 """
-from ._lib import BF16, F32, MfcError, lib  # noqa: F401  (importing loads libmfcnet_hip.so or raises)
+from ._lib import BF16, F16, F32, MfcError, lib  # noqa: F401  (importing loads libmfcnet_hip.so or raises)
 from .model import (HighResolutionNetHIP, HRNetMultiBasic, HRNetMultiLarge, get_multiframe_segmentation_model,  # noqa: F401
                     get_tooltip_segmentation_model)
 from .resunet import ResUnet_VB  # noqa: F401

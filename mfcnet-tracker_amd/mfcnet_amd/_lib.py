@@ -16,7 +16,12 @@ import torch  # noqa: F401  MUST precede the CDLL below: PyTorch bundles its own
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmfcnet_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
+
+
+def is16(dtype: int) -> bool:
+    """16-bit storage (bf16 or fp16): 8 channels per 16-byte granule, MFMA 16x16x32 kernels."""
+    return dtype in (BF16, F16)
 STAT_REPLICAS = 32
 
 # op kinds (mfc_op_kind)

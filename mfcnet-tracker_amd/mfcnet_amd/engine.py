@@ -38,6 +38,22 @@ def reduce_gradients(model, world_size, group=None):
         allreduce_grads(model, world_size, group=group, average=False)
 
 
+def loss_scale_for(model, output) -> float:
+    """Static loss scale of a step.  1 for fp32 / bf16 storage.  fp16 storage (BASELINE configs[4]) keeps gradients in IEEE half, whose
+    smallest normal is 6.1e-5 while a logit gradient of the mean-reduced loss is about 1 / (B*H*W) (4e-7 at B=8, 480x640): the loss is
+    multiplied by a power of two near B*H*W / 16 (largest logit gradient, class weight 1000, stays below ~64) and FlatAdam divides it
+    out in fp32.  `model.loss_scale` (a number) overrides the rule."""
+    from . import _lib as L
+    if getattr(model, "compute_dtype", None) != L.F16:
+        return 1.0
+    s = getattr(model, "loss_scale", None)
+    if s:
+        return float(s)
+    import math
+    B, _, H, W = output.shape
+    return float(2 ** max(0, round(math.log2(max(B * H * W / 16.0, 1.0)))))
+
+
 def train_step(model, optimizer, input, mask, optflow=None, depth=None, loss_wts=(0.7, 0.3),
                class_weights=DEFAULT_CLASS_WEIGHTS, world_size=1, group=None):
     """One optimisation step; returns (output logits, acc) with acc[26:29] = (nll, soft_jaccard, total) on the device.
@@ -46,9 +62,13 @@ def train_step(model, optimizer, input, mask, optflow=None, depth=None, loss_wts
     optimizer.zero_grad()
     output = _forward(model, input, optflow, depth)
     loss, acc = mfc_loss(output, mask, class_weights, loss_wts[0], loss_wts[1], global_batch=world_size > 1, group=group)
-    loss.backward()
+    scale = loss_scale_for(model, output)
+    (loss if scale == 1.0 else loss * scale).backward()
     reduce_gradients(model, world_size, group)
-    optimizer.step()
+    if scale == 1.0:
+        optimizer.step()
+    else:
+        optimizer.step(grad_scale=1.0 / scale)
     return output.detach(), acc
 
 

@@ -24,7 +24,8 @@ import torch.nn as nn
 from . import _lib as L
 from .arch import Entry, head_entries, hrnet_entries
 
-_DT = {"fp32": L.F32, "float32": L.F32, "f32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}
+_DT = {"fp32": L.F32, "float32": L.F32, "f32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16,
+       "fp16": L.F16, "float16": L.F16, "f16": L.F16, "half": L.F16}
 
 
 class _Node(nn.Module):

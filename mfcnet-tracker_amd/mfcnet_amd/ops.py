@@ -21,6 +21,8 @@ def dt_of(t: torch.Tensor) -> int:
         return L.F32
     if t.dtype == torch.bfloat16:
         return L.BF16
+    if t.dtype == torch.float16:
+        return L.F16
     raise L.MfcError(f"unsupported dtype {t.dtype}")
 
 

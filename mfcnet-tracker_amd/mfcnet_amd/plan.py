@@ -151,7 +151,7 @@ class Plan:
         self.base_prefix = "" if self.single else "base_model."
         self.has_flow, self.has_depth = has_flow, has_depth
         self.dtype = model.compute_dtype
-        self.esz = 2 if self.dtype == L.BF16 else 4
+        self.esz = 2 if L.is16(self.dtype) else 4
         self.E = 16 // self.esz
         self.base_training, self.head_training = base_training, head_training
         self.need_backward = need_backward
@@ -165,7 +165,7 @@ class Plan:
         self.lanes = getattr(model, "parallel_branches", True)      # branch-parallel lanes of the program (include/mfcnet_hip.h, mfc_op.lane)
         # BatchNorm-backward reduce passes folded into the epilogue of the data-gradient launch that completes the gradient (bf16):
         # mfc_conv_desc.bn_y / acc_src (include/mfcnet_hip.h)
-        self.fuse_bnred = bool(getattr(model, "fuse_bnbwd_reduce", True)) and self.dtype == L.BF16 and need_backward
+        self.fuse_bnred = bool(getattr(model, "fuse_bnbwd_reduce", True)) and L.is16(self.dtype) and need_backward
         self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc")}
         self.dry = dry
         self._build()                       # sizing pass
@@ -374,7 +374,7 @@ class Plan:
         for i, tm in enumerate(terms):
             d.src[i] = self.view(tm.t, tm.bn, tm.c_off)
         d.nsrc, d.relu, d.dtype, d.N, d.C, d.images_per_group = len(terms), 1 if relu else 0, self.dtype, out.N, Cs, out.ipg
-        if relu and self.need_backward and self.dtype == L.BF16 and self.mask_bits:
+        if relu and self.need_backward and L.is16(self.dtype) and self.mask_bits:
             # the backward of the summed terms (BatchNorm reduce, masked adds / up-sampling adjoints) needs only the sign of this
             # output: keep it as one bit per element (1/16 of the tensor) so that those passes read one tensor less
             if not out.bits:

@@ -69,7 +69,7 @@ class _Program:
     def __init__(self, model, B, H, W, device):
         self.m, self.B, self.H, self.W, self.device = model, B, H, W, device
         self.dtype = model.compute_dtype
-        self.esz = 2 if self.dtype == L.BF16 else 4
+        self.esz = 2 if L.is16(self.dtype) else 4
         self.E = 16 // self.esz
         self.arenas = {k: Arena(k) for k in ("act", "stats", "misc")}
         self._build()

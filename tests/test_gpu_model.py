@@ -142,7 +142,11 @@ def test_state_dict_roundtrip_and_errors(mfc):
 BF16_EVAL_TOL = 0.02        # max-abs, of the logit scale (mean-abs: 0.3 %); measured: max 1.0-1.5 %, mean 0.12-0.19 % (printed)
 
 
-def _bf16_vs_storage_oracle(mfc, cfg, width, single=False):
+FP16_EVAL_TOL = 0.004       # fp16 keeps 3 more mantissa bits than bf16: the same argument gives an 8x tighter ulp (measured, printed)
+_ST = {"bf16": (torch.bfloat16, BF16_EVAL_TOL), "fp16": (torch.float16, FP16_EVAL_TOL)}
+
+
+def _bf16_vs_storage_oracle(mfc, cfg, width, single=False, dtype="bf16"):
     """HIP bf16 (throughput mode) eval logits against the CPU oracle run with the SAME storage rounding (oracle `store_dtype=bfloat16`:
     every tensor the plan materialises is rounded to bf16 where the plan rounds it), so the storage rounding itself is common to both
     sides and only fp32 summation order differs.  That is NOT a 1e-6 difference at the output: a relative perturbation eps of a tensor
@@ -155,14 +159,14 @@ def _bf16_vs_storage_oracle(mfc, cfg, width, single=False):
     frames, flows, depths, mask = case_inputs(cfg)
     if single:
         sd = O.hashed_state(O.hrnet_table(width, 5, ""))
-        net = O.SingleNet(sd, width, 5, store_dtype=torch.bfloat16).eval()
-        m = mfc.HighResolutionNetHIP(num_classes=5, width=width, compute_dtype="bf16")
+        net = O.SingleNet(sd, width, 5, store_dtype=_ST[dtype][0]).eval()
+        m = mfc.HighResolutionNetHIP(num_classes=5, width=width, compute_dtype=dtype)
         args_o, args_m = (frames[0],), (frames[0].cuda(),)
     else:
         sd = O.hashed_state(O.mfcnet_table(cfg["model_type"], width, 5, cfg["T"], cfg["optflow"], cfg["depth"]))
-        net = O.Net(sd, cfg["model_type"], width, 5, cfg["T"], cfg["optflow"], cfg["depth"], store_dtype=torch.bfloat16).eval()
+        net = O.Net(sd, cfg["model_type"], width, 5, cfg["T"], cfg["optflow"], cfg["depth"], store_dtype=_ST[dtype][0]).eval()
         cls = mfc.HRNetMultiLarge if "Large" in cfg["model_type"] else mfc.HRNetMultiBasic
-        m = cls(num_classes=5, num_frames=cfg["T"], pretrained=False, width=width, compute_dtype="bf16",
+        m = cls(num_classes=5, num_frames=cfg["T"], pretrained=False, width=width, compute_dtype=dtype,
                 optflow_inputs=cfg["optflow"], depth_inputs=cfg["depth"])
         args_o, args_m = (frames,), (dev(frames),)
     m.load_state_dict(sd, strict=True)
@@ -172,8 +176,9 @@ def _bf16_vs_storage_oracle(mfc, cfg, width, single=False):
         y = m(*args_m, **({} if single else dict(optflow=dev(flows), depth=dev(depths)))).cpu()
     scale = float(ref.abs().max())
     mx, mean = float((y - ref).abs().max()), float((y - ref).abs().mean())
-    print(f"bf16 vs bf16-storage oracle [{cfg['name']} w{width}]: max {mx:.3e} mean {mean:.3e} of scale {scale:.3e}")
-    assert mx <= BF16_EVAL_TOL * scale and mean <= 0.15 * BF16_EVAL_TOL * scale, (mx, mean, scale)
+    tol = _ST[dtype][1]
+    print(f"{dtype} vs {dtype}-storage oracle [{cfg['name']} w{width}]: max {mx:.3e} mean {mean:.3e} of scale {scale:.3e}")
+    assert mx <= tol * scale and mean <= 0.15 * tol * scale, (mx, mean, scale)
     return m, net
 
 
@@ -219,6 +224,42 @@ def test_bf16_small_shapes_vs_storage_oracle_and_fp32(mfc):
     cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
     print("bf16 vs fp32 head-gradient cosine", cos, "loss", float(loss), float(l32))
     assert cos > 0.6 and bool(torch.isfinite(m._G).all()) and abs(float(loss.detach()) - float(l32.detach())) < 0.02
+
+
+def test_fp16_storage_eval_and_scaled_training_step(mfc):
+    """fp16 storage (BASELINE configs[4]'s dtype): the same kernels with the f16 MFMA and IEEE-half rounding.  Eval logits against the
+    oracle run with fp16 storage rounding (bound: the bf16 one / 5, three more mantissa bits); then one `engine.train_step`, which
+    scales the loss by a power of two so that the half-precision gradients stay normal (engine.loss_scale_for) and lets FlatAdam
+    divide it out: the unscaled head gradient must agree with the fp32 build's far better than bf16's does, nothing may overflow,
+    and the parameters must move by Adam's first step (lr per element where the gradient is not zero)."""
+    cfg = dict(name="fp16case", model_type="HRNetMulti-Large", T=3, optflow=True, depth=True, B=4, H=128, W=192, mode="train")
+    m, net = _bf16_vs_storage_oracle(mfc, cfg, 48, dtype="fp16")
+    frames, flows, depths, mask = case_inputs(cfg)
+    m.train()
+    opt = mfc.FlatAdam(m, lr=1e-4)
+    p0 = m._P.clone()
+    out, acc = mfc.train_step(m, opt, dev(frames), mask.cuda(), optflow=dev(flows), depth=dev(depths))
+    scale = mfc.engine.loss_scale_for(m, out)
+    assert scale == 2.0 ** round(np.log2(4 * 128 * 192 / 16.0)) and scale > 1
+    assert bool(torch.isfinite(m._G).all()) and bool(torch.isfinite(m._P).all())
+    g16 = (m.multiframe_net.multiframe_net[0].weight.grad / scale).cpu()
+    m32 = build(mfc, cfg, dtype="fp32")
+    m32.train()
+    l32, _ = mfc.mfc_loss(m32(dev(frames), optflow=dev(flows), depth=dev(depths)), mask.cuda())
+    l32.backward()
+    g32 = m32.multiframe_net.multiframe_net[0].weight.grad.cpu()
+    cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    rel = float((g16 - g32).norm() / g32.norm())
+    print(f"fp16 (loss scale {scale:g}) vs fp32 head gradient: cosine {cos:.4f}, relative L2 {rel:.3e}; loss {float(acc[28]):.5f} vs {float(l32):.5f}")
+    assert cos > 0.9 and abs(float(acc[28]) - float(l32.detach())) < 5e-3
+    moved = (m._P - p0).abs()
+    assert float(moved.max()) <= 1.001e-4 and float((moved > 0.9e-4 / 3).float().mean()) > 0.5       # |first Adam step| = lr (head) or lr / T (base group) where g != 0
+
+
+def test_fp16_config4_shape_eval_vs_storage_oracle(mfc):
+    """BASELINE.json configs[4]'s geometry and dtype on one clip: T=5, HRNet-w48, 720x960, fp16."""
+    cfg = dict(name="cfg4_fp16", model_type="HRNetMulti-Large", T=5, optflow=False, depth=False, B=1, H=720, W=960, mode="eval")
+    _bf16_vs_storage_oracle(mfc, cfg, 48, dtype="fp16")
 
 
 def test_t5_720x960_fp32_training_step_vs_oracle(mfc):

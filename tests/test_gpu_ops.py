@@ -24,14 +24,15 @@ def M():
     return mfcnet_amd, _lib, ops
 
 
-DT = [torch.float32, torch.bfloat16]
-TOL = {torch.float32: 2e-4, torch.bfloat16: 1.5e-2}
+DT = [torch.float32, torch.bfloat16, torch.float16]
+H16 = (torch.bfloat16, torch.float16)          # 16-bit storage: same kernels, layouts and fusions
+TOL = {torch.float32: 2e-4, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}
 
 
 def rnd(dtype, *shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(*shape, generator=g) * scale
-    return x.to(dtype).float() if dtype == torch.bfloat16 else x
+    return x.to(dtype).float() if dtype in H16 else x
 
 
 def relerr(a, b):
@@ -84,8 +85,8 @@ def test_conv_fused_bn_relu_input_and_stats(M, dtype, cfg):
     coef = torch.zeros(G, 4, Cin)
     coef[:, 0], coef[:, 1] = scale, shift
     xa = torch.cat([F.relu(x[g * 2:(g + 1) * 2] * scale[g].view(1, -1, 1, 1) + shift[g].view(1, -1, 1, 1)) for g in range(G)])
-    if dtype == torch.bfloat16:
-        xa = xa.bfloat16().float()
+    if dtype in H16:
+        xa = xa.to(dtype).float()
     ref = F.conv2d(xa, w, None, padding=k // 2)
     stats = torch.zeros(L.STAT_REPLICAS, G, 2, Cout, device="cuda")
     y = ops.conv2d(ops.to_nhwc(x, dtype), w.cuda(), k, 1, in_coef=coef.cuda(), in_relu=True, ipg=2, stats=stats)
@@ -149,29 +150,30 @@ FUSED_DG_CASES = [  # N, G, Cin, Cout, k, s, H, W, mask mode, accumulate from an
     (6, 3, 64, 32, 1, 1, 20, 28, 2, False), (3, 1, 32, 64, 3, 2, 23, 30, 2, True)]
 
 
+@pytest.mark.parametrize("dt16", H16, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", FUSED_DG_CASES)
-def test_dgrad_fused_bn_backward_reduce(M, case):
+def test_dgrad_fused_bn_backward_reduce(dt16, M, case):
     """mfc_conv_desc.bn_y / acc_src: a data-gradient launch that masks its result, accumulates the BatchNorm-backward statistics
     (sum g*m, sum g*m*yhat per group and channel) in its epilogue and reads its running sum from another tensor -- against autograd's
     data gradient with the mask / the sums applied on the CPU (the work mfc_bnbwd_reduce otherwise does in a second sweep)."""
     _, L, ops = M
     N, G, Cin, Cout, k, s, H, W, mode, acc = case
     ipg = N // G
-    x = rnd(torch.bfloat16, N, Cin, H, W, seed=51).requires_grad_(True)
-    w = rnd(torch.bfloat16, Cout, Cin, k, k, seed=52, scale=1.0 / np.sqrt(Cin * k * k))
+    x = rnd(dt16, N, Cin, H, W, seed=51).requires_grad_(True)
+    w = rnd(dt16, Cout, Cin, k, k, seed=52, scale=1.0 / np.sqrt(Cin * k * k))
     yo = F.conv2d(x, w, None, stride=s, padding=k // 2)
-    dy = rnd(torch.bfloat16, *yo.shape, seed=53)
+    dy = rnd(dt16, *yo.shape, seed=53)
     yo.backward(dy)
-    base = rnd(torch.bfloat16, N, Cin, H, W, seed=54) if acc else torch.zeros(N, Cin, H, W)
+    base = rnd(dt16, N, Cin, H, W, seed=54) if acc else torch.zeros(N, Cin, H, W)
     g_ref = x.grad + base                                      # the completed gradient
-    ybn = rnd(torch.bfloat16, N, Cin, H, W, seed=55)           # pre-BN tensor of the BatchNorm whose backward is fused
+    ybn = rnd(dt16, N, Cin, H, W, seed=55)           # pre-BN tensor of the BatchNorm whose backward is fused
     g = torch.Generator().manual_seed(56)
     scale, shift = torch.rand(G, Cin, generator=g) + 0.5, torch.randn(G, Cin, generator=g) * 0.3
     mean, rstd = torch.randn(G, Cin, generator=g) * 0.2, torch.rand(G, Cin, generator=g) + 0.5
     coef = torch.stack([scale, shift, mean, rstd], 1).contiguous()          # [G][4][Cin]
     e5 = lambda t: t.view(G, 1, Cin, 1, 1)
     yv = ybn.view(G, ipg, Cin, H, W)
-    signsrc = rnd(torch.bfloat16, N, Cin, H, W, seed=57)
+    signsrc = rnd(dt16, N, Cin, H, W, seed=57)
     if mode == 2:
         m = ((yv * e5(scale) + e5(shift)) > 0).float()
     elif mode == 3:
@@ -182,9 +184,9 @@ def test_dgrad_fused_bn_backward_reduce(M, case):
     s1_ref = gm_ref.sum((1, 3, 4))
     s2_ref = (gm_ref * (yv - e5(mean)) * e5(rstd)).sum((1, 3, 4))
     # ---- the launch(es)
-    dyd, yd, srcd = ops.to_nhwc(dy, torch.bfloat16), ops.to_nhwc(ybn, torch.bfloat16), ops.to_nhwc(base, torch.bfloat16)
-    bits = pack_sign_bits(ops.to_nhwc(signsrc, torch.bfloat16))
-    dx = torch.zeros(N, H, W, Cin, dtype=torch.bfloat16, device="cuda")
+    dyd, yd, srcd = ops.to_nhwc(dy, dt16), ops.to_nhwc(ybn, dt16), ops.to_nhwc(base, dt16)
+    bits = pack_sign_bits(ops.to_nhwc(signsrc, dt16))
+    dx = torch.zeros(N, H, W, Cin, dtype=dt16, device="cuda")
     bstats = torch.zeros(L.STAT_REPLICAS, G, 2, Cin, device="cuda")
     coef_d = coef.cuda()
     Ho, Wo, pad = yo.shape[2], yo.shape[3], k // 2
@@ -192,14 +194,14 @@ def test_dgrad_fused_bn_backward_reduce(M, case):
     classes = [(0, 0)] if s == 1 else [(a, b) for a in range(2) for b in range(2)]
     for (ph, pw) in classes:
         if s == 1:
-            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), L.BF16, N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, H, W,
+            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, H, W,
                            k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, ipg, 1 if acc else 0, 0, 0)
             mode_s, cls = "dgrad", (0, 0)
         else:
             ta, _, dh0 = ops.s2_class(k, pad, ph)
             tb, _, dw0 = ops.s2_class(k, pad, pw)
             Hl, Wl = (H - ph + 1) // 2, (W - pw + 1) // 2
-            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), L.BF16, N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, Hl, Wl,
+            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, Hl, Wl,
                            ta, tb, dh0, dw0, 1, 2, 2, ph, pw, 0, ipg, 1 if acc else 0, 0, 0)
             mode_s, cls = "dgrad_s2", (ph, pw)
         d.flags = L.CONV_WANT_FA
@@ -214,10 +216,10 @@ def test_dgrad_fused_bn_backward_reduce(M, case):
         launched += 1
     torch.cuda.synchronize()
     gm = ops.to_nchw(dx, Cin).cpu().view(G, ipg, Cin, H, W)
-    assert relerr(gm, gm_ref) < 2 * TOL[torch.bfloat16]
+    assert relerr(gm, gm_ref) < 2 * TOL[dt16]
     st = bstats.sum(0).cpu()
-    assert relerr(st[:, 0], s1_ref) < 5 * TOL[torch.bfloat16]
-    assert relerr(st[:, 1], s2_ref) < 5 * TOL[torch.bfloat16]
+    assert relerr(st[:, 0], s1_ref) < 5 * TOL[dt16]
+    assert relerr(st[:, 1], s2_ref) < 5 * TOL[dt16]
     # a launch that cannot take the fusion must refuse it rather than drop it
     d2 = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), L.F32, N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, H, W,
                     k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, ipg, 0, 0, 0)
@@ -255,9 +257,10 @@ def test_conv_wgrad(M, case, dtype, tr):
 DMA_CASES = [(3, 32, 32, 15, 20), (2, 64, 32, 23, 30), (2, 32, 64, 5, 6), (4, 96, 96, 12, 40), (2, 32, 32, 4, 8), (6, 64, 64, 17, 9)]
 
 
+@pytest.mark.parametrize("dt16", H16, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("xf", [False, True])
 @pytest.mark.parametrize("case", DMA_CASES)
-def test_wgrad_dma_kernel(M, case, xf):
+def test_wgrad_dma_kernel(dt16, M, case, xf):
     """conv_wgrad_dma.hip (3x3 / stride 1, channel counts that are multiples of 32, bf16): ragged images (partial 4x8 sub-tiles on both
     axes, images narrower than a tile, every tile an edge tile), several channel blocks, with and without the fused BatchNorm + ReLU
     of the producer (two statistic groups); against autograd on the same bf16-rounded operands, and against the register-staged
@@ -265,27 +268,27 @@ def test_wgrad_dma_kernel(M, case, xf):
     _, L, ops = M
     N, Cin, Cout, H, W = case
     G = 2 if N % 2 == 0 else 1
-    x = rnd(torch.bfloat16, N, Cin, H, W, seed=41)
+    x = rnd(dt16, N, Cin, H, W, seed=41)
     xa, coef = x, None
     if xf:
         scale, shift = torch.rand(G, Cin) + 0.5, torch.randn(G, Cin) * 0.3
         coef = torch.zeros(G, 4, Cin)
         coef[:, 0], coef[:, 1] = scale, shift
         xa = F.relu(x.view(G, N // G, Cin, H, W) * scale.view(G, 1, Cin, 1, 1) + shift.view(G, 1, Cin, 1, 1)).reshape(N, Cin, H, W)
-        xa = xa.bfloat16().float()
-    w = rnd(torch.bfloat16, Cout, Cin, 3, 3, seed=42, scale=0.05).requires_grad_(True)
+        xa = xa.to(dt16).float()
+    w = rnd(dt16, Cout, Cin, 3, 3, seed=42, scale=0.05).requires_grad_(True)
     y = F.conv2d(xa, w, None, padding=1)
-    dy = rnd(torch.bfloat16, *y.shape, seed=43)
+    dy = rnd(dt16, *y.shape, seed=43)
     y.backward(dy)
     res = []
     for flag in (1, 0):
         L.lib.mfc_set_flag(29, flag)
         try:
-            res.append(ops.conv2d_wgrad(ops.to_nhwc(x, torch.bfloat16), ops.to_nhwc(dy, torch.bfloat16), Cout, Cin, 3, 1,
+            res.append(ops.conv2d_wgrad(ops.to_nhwc(x, dt16), ops.to_nhwc(dy, dt16), Cout, Cin, 3, 1,
                                         in_coef=coef.cuda() if xf else None, in_relu=xf, ipg=N // G).cpu())
         finally:
             L.lib.mfc_set_flag(29, 1)
-    assert relerr(res[0], w.grad) < TOL[torch.bfloat16]
+    assert relerr(res[0], w.grad) < TOL[dt16]
     assert relerr(res[0], res[1]) < 1e-4            # same products, fp32 accumulation in another order
 
 
@@ -318,8 +321,8 @@ def test_wgrad_1x1_fused_input_transform_groups(M, dtype, cfg):
     coef = torch.zeros(G, 4, ops.rup(Cin, 8))
     coef[:, 0, :Cin], coef[:, 1, :Cin] = scale, shift
     xa = torch.cat([F.relu(x[g * 2:(g + 1) * 2] * scale[g].view(1, -1, 1, 1) + shift[g].view(1, -1, 1, 1)) for g in range(G)])
-    if dtype == torch.bfloat16:
-        xa = xa.bfloat16().float()
+    if dtype in H16:
+        xa = xa.to(dtype).float()
     w = rnd(dtype, Cout, Cin, 1, 1, seed=22, scale=0.05).requires_grad_(True)
     y = F.conv2d(xa, w, None)
     dy = rnd(dtype, *y.shape, seed=23)
@@ -388,11 +391,11 @@ def test_combine_residual_bilinear(M, dtype):
     d.src[0], d.src[1], d.src[2], d.src[3] = ops.view(ta), ops.view(tb, cbd), ops.view(tc, ccd), ops.view(te)
     d.nsrc, d.relu, d.dtype, d.N, d.C, d.images_per_group = 4, 1, ops.dt_of(ta), N, Cc, N
     bits = torch.zeros(out.numel() // 8, dtype=torch.uint8, device="cuda")
-    if dtype == torch.bfloat16:
+    if dtype in H16:
         d.maskbits = bits.data_ptr()
     L.call(L.lib.mfc_combine_fwd, d)
     assert relerr(ops.to_nchw(out, Cc).cpu(), ref) < TOL[dtype]
-    if dtype == torch.bfloat16:      # the 1-bit image of the output's sign, for the backward pass
+    if dtype in H16:      # the 1-bit image of the output's sign, for the backward pass
         assert torch.equal(bits, pack_sign_bits(out))
 
 
@@ -430,7 +433,7 @@ def test_bn_backward(M, dtype, mode):
     if mode == 1:
         d.mask = ops.view(ta)
     if mode == 3:            # the 1-bit image of the same mask (bf16 only)
-        if dtype != torch.bfloat16:
+        if dtype not in H16:
             pytest.skip("1-bit masks are a bf16 feature")
         bits = pack_sign_bits(ta)
         d.mask = L.View(bits.data_ptr(), 0, ta.shape[1], ta.shape[2], ta.shape[3], 0)
@@ -496,7 +499,7 @@ def test_mask_add_adjoint_bilinear(M, dtype, hw):
         d.dst, d.scratch = ops.view(dst2), scratch.data_ptr()
         L.call(L.lib.mfc_mask_add, d)
         assert relerr(ops.to_nchw(dst2, Cc).cpu() - 1.0, src.grad) < TOL[dtype] * 2
-    if dtype == torch.bfloat16:     # the mask as a 1-bit image (mask_mode 3), every kernel form
+    if dtype in H16:     # the mask as a 1-bit image (mask_mode 3), every kernel form
         bits = pack_sign_bits(tout)
         for use_scratch in ((False, True) if (hs, ws) != (H, W) else (False,)):
             dst3 = torch.ones(N, hs, ws, Cc, dtype=dtype, device="cuda")
@@ -536,7 +539,7 @@ def test_head_gather_fwd_bwd(M, dtype, flow, depth):
     d.dtype, d.B, d.T, d.nc, d.Hs, d.Ws, d.Lp, d.H, d.W, d.Cp, d.warp = ops.dt_of(tl), B, T, nc, Hs, Ws, 8, H, W, Cp, 0
     L.call(L.lib.mfc_head_gather_fwd, d)
     got = ops.to_nchw(xh, cin).cpu()
-    want = ref.detach().to(dtype).float() if dtype == torch.bfloat16 else ref.detach()
+    want = ref.detach().to(dtype).float() if dtype in H16 else ref.detach()
     assert relerr(got, want) < TOL[dtype]
     assert float(xh[..., cin:].float().abs().max() if Cp > cin else 0) == 0
     g = rnd(dtype, B, cin, H, W, seed=27)
