@@ -28,6 +28,8 @@ def _demangle(name):
     while i < len(rest) and rest[i] != "E":
         if rest.startswith("DF16b", i):
             args.append("__bf16"); i += 5
+        elif rest.startswith("DF16_", i):
+            args.append("_Float16"); i += 5
         elif rest[i] == "f":
             args.append("float"); i += 1
         elif rest.startswith("Lb", i):
@@ -41,10 +43,23 @@ def _demangle(name):
     return f"{base}<{', '.join(args)}>"
 
 
+_mangled_of = {}     # rocprofv3 display name -> mangled name (its own demangler garbles DF16b / DF16_ template arguments)
+
+
+def load_symbols(db):
+    for (t,) in db.execute("select name from sqlite_master where type='table' and name like 'rocpd_info_kernel_symbol%'").fetchall():
+        for kn, dn in db.execute(f"select kernel_name, display_name from {t}"):
+            if kn and dn and kn.startswith("_Z"):
+                _mangled_of[dn] = kn[:-3] if kn.endswith(".kd") else kn
+
+
 def short(name):
     """kernel name as bench.py's profiler rows spell it: demangled, no return type, no argument list"""
     if name not in _demangled:
-        out = _demangle(name) if name.startswith("_Z") else name
+        src = _mangled_of.get(name, name)
+        out = _demangle(src) if src.startswith("_Z") else src
+        if out.startswith("_Z"):
+            out = name
         out = re.sub(r"^void ", "", out)
         depth, cut = 0, len(out)
         for i, ch in enumerate(out):           # cut at the argument list's '(' (outside template brackets)
@@ -64,6 +79,7 @@ SETUP = ("__amd_rocclr_", "at::native::", "pack_weights_kernel")      # model se
 
 def kernel_stats(db_path):
     db = sqlite3.connect(db_path)
+    load_symbols(db)
     rows = db.execute("select name, duration from kernels").fetchall()
     agg = defaultdict(list)
     for n, d in rows:
@@ -80,6 +96,7 @@ def kernel_stats(db_path):
 
 def pmc_avg(db_path, counter):
     db = sqlite3.connect(db_path)
+    load_symbols(db)
     rows = db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
     agg = defaultdict(list)
     for n, v in rows:
