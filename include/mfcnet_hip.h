@@ -391,6 +391,12 @@ int mfc_confusion_counts(const float* outputs /* NCHW fp32 [B, nc, H, W] */, con
  * ------------------------------------------------------------------------------------ */
 int mfc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int32_t step, float grad_scale, void* stream);
+/* Overflow guard of a loss-scaled (fp16) step, without a host round trip: mfc_grad_check sets flag[0] = 1 (after clearing it on the
+ * stream) iff some element of g is Inf or NaN and counts such steps in flag[1]; mfc_adam_step_guarded is mfc_adam_step that leaves
+ * p, m, v untouched when *skip_flag != 0 (what torch.cuda.amp.GradScaler.step does on the host).  flag: DEVICE int32[2]. */
+int mfc_grad_check(const float* g, int64_t n, int32_t* flag, void* stream);
+int mfc_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, int32_t step, float grad_scale, const int32_t* skip_flag, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Program interpreter: runs a whole forward or backward pass (hundreds of the calls above)

@@ -180,9 +180,10 @@ extern "C" int mfc_confusion_counts(const float* outputs, const int64_t* target,
 
 // ------------------------------------------------------------------ Adam
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float step_size,
-                                                   float beta1, float beta2, float eps, float inv_bc2_sqrt, float gscale) {
+                                                   float beta1, float beta2, float eps, float inv_bc2_sqrt, float gscale, const int* skip) {
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
+    if (skip && *skip) return;               // (guarded step: the gradients of this step are not finite -- leave p, m, v alone)
     if (i + 4 <= n) {
         float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
         float* pp = (float*)&P; float* gg = (float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
@@ -204,8 +205,50 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     }
 }
 
+// any element of g not finite -> flag[0] = 1, flag[1] += 1 (count of such checks); flag[0] is cleared first, on the stream
+__global__ __launch_bounds__(256) void grad_check_kernel(const float* g, long n, int* flag) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int mine = 0;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const float4 v = *(const float4*)(g + i);
+            mine |= (int)!(fabsf(v.x) <= 3.4e38f) | (int)!(fabsf(v.y) <= 3.4e38f) | (int)!(fabsf(v.z) <= 3.4e38f) | (int)!(fabsf(v.w) <= 3.4e38f);
+        } else {
+            for (long k = i; k < n; ++k) mine |= (int)!(fabsf(g[k]) <= 3.4e38f);
+        }
+    }
+    if (mine) bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && bad) { if (atomicExch(flag, 1) == 0) atomicAdd(flag + 1, 1); }
+}
+
+extern "C" int mfc_grad_check(const float* g, int64_t n, int32_t* flag, void* stream) {
+    if (!g || !flag || n <= 0 || ((uintptr_t)g & 15)) return MFC_ERR_INVALID_ARG;
+    if (hipMemsetAsync(flag, 0, 4, (hipStream_t)stream) != hipSuccess) return MFC_ERR_LAUNCH;
+    long blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (g_mfc_prof_on == 1) mfc_prof_before((hipStream_t)stream, "grad_check_kernel", 0.0, 4.0 * (double)n);
+    hipLaunchKernelGGL(grad_check_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, (long)n, (int*)flag);
+    MFC_PROF_END((hipStream_t)stream);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+static int adam_step_impl(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, int32_t step, float grad_scale, const int32_t* skip_flag, void* stream);
 extern "C" int mfc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                              float eps, int32_t step, float grad_scale, void* stream) {
+    return adam_step_impl(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, nullptr, stream);
+}
+extern "C" int mfc_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                     float eps, int32_t step, float grad_scale, const int32_t* skip_flag, void* stream) {
+    if (!skip_flag) return MFC_ERR_INVALID_ARG;
+    return adam_step_impl(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, skip_flag, stream);
+}
+static int adam_step_impl(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, int32_t step, float grad_scale, const int32_t* skip_flag, void* stream) {
     if (!p || !g || !m || !v || n <= 0 || step < 1) return MFC_ERR_INVALID_ARG;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MFC_ERR_INVALID_ARG;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -213,7 +256,7 @@ extern "C" int mfc_adam_step(float* p, const float* g, float* m, float* v, int64
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     const long blocks = ((n + 3) / 4 + 255) / 256;
     if (g_mfc_prof_on == 1) mfc_prof_before((hipStream_t)stream, "adam_kernel", 0.0, 28.0 * (double)n);
-    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale, (const int*)skip_flag);
     MFC_PROF_END((hipStream_t)stream);
     MFC_CHECK_LAUNCH();
     return MFC_OK;

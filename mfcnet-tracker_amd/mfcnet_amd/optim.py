@@ -43,29 +43,47 @@ class FlatAdam(torch.optim.Optimizer):
         self.m = torch.zeros_like(model._P)
         self.v = torch.zeros_like(model._P)
         self._arena = model._P
+        self._flag = None            # device int32[2] of the overflow guard: [this step's gradients not finite, number of such steps]
 
     @property
     def lrs(self):
         return {g["name"]: g["lr"] for g in self.param_groups}
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, guard=None):
+        """`grad_scale` multiplies the gradients inside the kernel (1 / loss scale of an fp16 step).  `guard` (default: on whenever
+        grad_scale != 1): check the whole gradient arena for Inf / NaN on the device first and make the update a no-op when there is
+        one -- an overflowed half-precision gradient must not reach the moments.  No host synchronisation; `skipped_steps()` reads
+        the counter."""
         loss = closure() if closure is not None else None
         mdl = self.model
         if mdl._P is not self._arena:
             raise L.MfcError("model was moved after the optimizer was built; rebuild FlatAdam")
         self.step_count += 1
         st = L.stream_ptr()
+        if guard is None:
+            guard = grad_scale != 1.0
+        if guard:
+            if self._flag is None:
+                self._flag = torch.zeros(2, dtype=torch.int32, device=mdl._P.device)
+            L.check(L.lib.mfc_grad_check(mdl._G.data_ptr(), mdl._G.numel(), self._flag.data_ptr(), st), "mfc_grad_check")
         for g in self.param_groups:
             a, b = g["segment"]
             for p in g["params"]:
                 if not p.requires_grad:                 # frozen inside a trainable segment: zero gradient -> zero moments -> no update
                     off = (p.data_ptr() - mdl._P.data_ptr()) // 4
                     mdl._G[off:off + p.numel()].zero_()
-            L.check(L.lib.mfc_adam_step(mdl._P.data_ptr() + 4 * a, mdl._G.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
-                                        self.v.data_ptr() + 4 * a, b - a, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
-                                        self.step_count, grad_scale, st), "mfc_adam_step")
+            args = (mdl._P.data_ptr() + 4 * a, mdl._G.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, b - a,
+                    float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self.step_count, grad_scale)
+            if guard:
+                L.check(L.lib.mfc_adam_step_guarded(*args, self._flag.data_ptr(), st), "mfc_adam_step_guarded")
+            else:
+                L.check(L.lib.mfc_adam_step(*args, st), "mfc_adam_step")
         return loss
+
+    def skipped_steps(self) -> int:
+        """guarded steps whose gradients were not finite (one host read)"""
+        return 0 if self._flag is None else int(self._flag[1])
 
     # ---- checkpointing (utils/model_utils.py:6-12 stores optimizer.state_dict() next to the model's) ----
     def state_dict(self):

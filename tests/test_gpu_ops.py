@@ -716,6 +716,36 @@ def test_wgrad_batch_matches_single_launches(M):
     assert L.lib.mfc_conv2d_wgrad_batch(descs, n, L.stream_ptr()) == -1
 
 
+def test_guarded_adam_skips_a_step_with_non_finite_gradients(M):
+    """mfc_grad_check + mfc_adam_step_guarded (the overflow guard of a loss-scaled fp16 step): finite gradients -> the same update as
+    mfc_adam_step, bit for bit; one Inf or NaN anywhere in the arena -> parameters and both moments untouched, counter incremented."""
+    _, L, ops = M
+    n = 100003
+    g0 = torch.Generator().manual_seed(9)
+    p0, g = torch.randn(n, generator=g0).cuda(), (torch.randn(n, generator=g0) * 512).cuda()
+    flag = torch.zeros(2, dtype=torch.int32, device="cuda")
+
+    def run(guarded, grad):
+        p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        args = (p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0 / 512)
+        if guarded:
+            L.check(L.lib.mfc_grad_check(grad.data_ptr(), n, flag.data_ptr(), L.stream_ptr()), "check")
+            L.check(L.lib.mfc_adam_step_guarded(*args, flag.data_ptr(), L.stream_ptr()), "adam")
+        else:
+            L.check(L.lib.mfc_adam_step(*args, L.stream_ptr()), "adam")
+        torch.cuda.synchronize()
+        return p, m, v
+    a, b = run(False, g), run(True, g)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and flag.tolist() == [0, 0] and not torch.equal(a[0], p0)
+    for bad, where in ((float("inf"), 0), (float("nan"), n - 1), (-float("inf"), n // 2)):
+        gb = g.clone(); gb[where] = bad
+        p, m, v = run(True, gb)
+        assert torch.equal(p, p0) and float(m.abs().max()) == 0 and float(v.abs().max()) == 0 and int(flag[0]) == 1
+    assert int(flag[1]) == 3
+    run(True, g)
+    assert flag.tolist() == [0, 3]
+
+
 def test_adam_matches_torch(M):
     _, L, ops = M
     n = 10007

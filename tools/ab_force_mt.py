@@ -1,0 +1,31 @@
+"""Geometry A/B for one convolution shape: mfc_set_flag(2, MT) forces the pixel tiles per wave, flag 19 the 8-wave weight."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+from mfcnet_amd import _lib as L, ops
+from sweep_conv2 import time_op
+SHAPES = [(24, 48, 48, 3, 120, 160), (24, 96, 96, 3, 60, 80), (24, 32, 32, 3, 120, 160)]
+for (N, Cin, Cout, k, H, W) in SHAPES:
+    for xf in (0, 1):
+        pad = k // 2
+        x = torch.randn(N, H, W, ops.rup(Cin, 8), device="cuda").to(torch.bfloat16)
+        w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
+        out = torch.zeros(N, H, W, ops.rup(Cout, 8), dtype=torch.bfloat16, device="cuda")
+        stats = torch.zeros(L.STAT_REPLICAS, 3, 2, out.shape[3], device="cuda")
+        coef = torch.rand(3, 4, x.shape[3], device="cuda")
+        line = f"{(N,Cin,Cout,k,H,W)} xf={xf}"
+        for mt, nw8 in ((0, 90), (2, 90), (4, 90), (2, 0), (4, 0)):
+            L.lib.mfc_set_flag(2, mt); L.lib.mfc_set_flag(19, nw8)
+            d = L.ConvDesc(x.data_ptr(), 0, out.data_ptr(), 0, coef.data_ptr() if xf else 0, stats.data_ptr(), L.BF16, N, H, W, x.shape[3], Cin, H, W,
+                           out.shape[3], Cout, H, W, k, k, -pad, -pad, 1, 1, 1, 0, 0, 1 if xf else 0, N // 3, 0, 0, 0)
+            try:
+                wp = ops.pack_weight(w, d, "fwd"); d.wp = wp.data_ptr()
+                lay = L.conv_layout(d)
+                op = L.Op(); op.kind = L.OP_CONV; op.u.conv = d
+                line += f" | mt{mt}/nw8={nw8}: NW{lay.NW} MT{lay.MT} NT{lay.NT16//16} KG{lay.KG}x{lay.nchunks} {lay.lds_bytes//1024}K {time_op(op):5.1f}"
+            except Exception as e:
+                line += f" | mt{mt}/nw8={nw8}: {type(e).__name__}"
+        L.lib.mfc_set_flag(2, 0); L.lib.mfc_set_flag(19, 90)
+        print(line, flush=True)
