@@ -48,6 +48,16 @@ def test_bench_line_contract():
     assert d["config"]["launcher"] == "bench.py" and d["config"]["ranks"] == 1
 
 
+def test_bench_fp16_line():
+    """`--dtype fp16` (BASELINE.json configs[4]'s dtype): loss-scaled, guarded steps; the line says fp16 and the loss stays finite."""
+    _need_gpu()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dtype", "fp16", "--no-prof"] + SMALL, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["dtype"] == "fp16" and 0.0 < d["config"]["final_loss"] < 20.0 and d["value"] > 0
+
+
 def test_bench_two_ranks_share_the_gpu_over_gloo():
     _need_gpu()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
