@@ -49,7 +49,12 @@ typedef enum {
     MFC_ERR_LAUNCH = -3
 } mfc_status;
 
-#define MFC_STAT_REPLICAS 32   /* rows the per-channel sum atomics are spread over */
+#define MFC_STAT_REPLICAS 8    /* rows the per-channel sum atomics are spread over (8 / 16 / 32 measured on the full step: 39.3 / 39.5 / 39.7 ms -- every finalize reads all rows) */
+/* Statistic sums (BatchNorm / GroupNorm forward sums, BatchNorm-backward sums) are fp64 cells added to with fp64 atomics: the fp32 partial
+ * sums of the workgroups then add up to the same value whatever order the workgroups arrive in.  With fp32 cells the order noise of the
+ * atomics (1e-7 relative) is amplified by var = E[x^2] - mean^2 on channels whose variance is small against their mean, and a bf16 training-mode
+ * forward then has run-to-run differences of 15 % of the logit scale at low resolutions (tools/train_noise.py); with fp64 cells it repeats. */
+typedef double mfc_stat_t;
 
 /* ---- BatchNorm coefficient block: fp32 [G][4][Cp] = scale, shift, mean, rstd ---- */
 #define MFC_COEF_SCALE 0
@@ -86,7 +91,7 @@ typedef struct {
     void* out;               /* T [N, Hout, Wout, Cout_p] */
     const float* bias;       /* [>=Cout] or NULL */
     const float* in_coef;    /* [G][4][Cin_p] or NULL (no input transform) */
-    float* out_stats;        /* [MFC_STAT_REPLICAS][G][2][Cout_p] or NULL */
+    mfc_stat_t* out_stats;   /* [MFC_STAT_REPLICAS][G][2][Cout_p] or NULL */
     int32_t dtype;
     int32_t N, Hin, Win, Cin_p, Cin;       /* Cin = channels actually reduced over (<= Cin_p) */
     int32_t Hout, Wout, Cout_p, Cout;      /* physical output tensor */
@@ -195,7 +200,7 @@ int mfc_unpack_wgrad(const mfc_unpack_job* jobs_dev, int32_t njobs, int32_t tota
  * num_batches_tracked += G.  training=0: coefficients from the running stats.
  * ------------------------------------------------------------------------------------ */
 typedef struct {
-    const float* stats;      /* [R][G][2][Cp] (training) */
+    const mfc_stat_t* stats; /* [R][G][2][Cp] (training) */
     float* coef;             /* out [G][4][Cp] */
     const float* gamma;      /* [C] */
     const float* beta;       /* [C] */
@@ -249,7 +254,7 @@ int mfc_combine_fwd(const mfc_combine_desc* d, void* stream);
  * ------------------------------------------------------------------------------------ */
 int mfc_ws_normalize(const float* w, float* w_out, int32_t Cout, int32_t per_out, float eps, void* stream);
 typedef struct {
-    const float* stats;      /* [MFC_STAT_REPLICAS][N][2][Cp] */
+    const mfc_stat_t* stats; /* [MFC_STAT_REPLICAS][N][2][Cp] */
     float* coef;             /* out [N][4][Cp] */
     const float* gamma;      /* [C] */
     const float* beta;       /* [C] */
@@ -277,7 +282,7 @@ typedef struct {
     mfc_view y;              /* conv output (pre-BN); y.coef = this BN's coefficient block */
     mfc_view mask;           /* mode 1: tensor whose sign gives the ReLU mask; mode 3 (bf16): its 1-bit image written by mfc_combine_fwd (ptr = bits) */
     mfc_view dy;             /* apply: destination (may alias g); reduce: optional g*m output */
-    float* bstats;           /* [R][G][2][Cp] */
+    mfc_stat_t* bstats;      /* [R][G][2][Cp] */
     const float* bcoef;      /* [G][2][Cp] c1, c2 (apply) */
     int32_t mask_mode, dtype, N, C, images_per_group, accumulate;
     /* apply only, optional: finalize fused into the apply launch (fin_dgamma set).  Every workgroup first sums the replica
@@ -294,7 +299,7 @@ int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream);
 int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream);
 
 typedef struct {
-    const float* bstats;     /* [R][G][2][Cp] */
+    const mfc_stat_t* bstats; /* [R][G][2][Cp] */
     float* bcoef;            /* out [G][2][Cp] */
     float* dgamma;           /* [C] (overwritten) */
     float* dbeta;            /* [C] (overwritten) */

@@ -21,7 +21,7 @@
 #include "common.h"
 
 struct GemmK {
-    const char* in; const char* wp; char* out; const float* bias; float* out_stats; const float* in_coef;
+    const char* in; const char* wp; char* out; const float* bias; mfc_stat_t* out_stats; const float* in_coef;
     int in_relu;
     int M, Cin_p, Cin_g, Cout_p, Cout;
     int nchunks, Yblocks, ntiles, tiles_per_block;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
             const int w0 = (cl >> 6) * 2, ch = cl & 63;
             const float s = rd[(w0 * 2 + which) * 64 + ch] + rd[((w0 + 1) * 2 + which) * 64 + ch];
             const int co = y * G_BN + cl;
-            if (co < p.Cout_p) atomicAdd(p.out_stats + (((size_t)(Lb % MFC_R) * p.G + red_grp) * 2 + which) * p.Cout_p + co, s);
+            if (co < p.Cout_p) atomicAdd(p.out_stats + (((size_t)(Lb % MFC_R) * p.G + red_grp) * 2 + which) * p.Cout_p + co, (mfc_stat_t)s);
         }
         __syncthreads();
         for (int i = tid; i < G_MAXYB * G_RED1; i += 512) red[i] = 0.f;

@@ -25,7 +25,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 struct ConvK {
     const char* in; const char* wp; char* out;
-    const float* bias; const float* in_coef; float* out_stats;
+    const float* bias; const float* in_coef; mfc_stat_t* out_stats;
     int N, Hin, Win, Cin_p, Cin_g;      // Cin_g: granules to reduce over
     int Hout, Wout, Cout_p, Cout;
     int Hl, Wl, TA, TB, dh0, dw0, s;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) s += rd[(w * 2 + which) * NT16 + cl];
-                atomicAdd(p.out_stats + (((size_t)red_rep * p.G + red_grp) * 2 + which) * p.Cout_p + red_n0 + cl, s);
+                atomicAdd(p.out_stats + (((size_t)red_rep * p.G + red_grp) * 2 + which) * p.Cout_p + red_n0 + cl, (mfc_stat_t)s);
             }
         }
         red_pending = false;

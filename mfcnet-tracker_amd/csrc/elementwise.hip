@@ -15,17 +15,15 @@
 static inline double view_bytes(const mfc_view& v, int N, int C, int esz) { return v.ptr ? (double)N * v.H * v.W * C * esz : 0.0; }
 
 // ------------------------------------------------------------------ BN finalize
-// sum of the R replica rows of one (group, stat, channel) cell: 32 independent loads in flight
-__device__ inline double replica_sum(const float* base, size_t stride) {
-    float p[8];
+// sum of the R = MFC_STAT_REPLICAS replica rows of one (group, stat, channel) cell: all loads in flight at once
+__device__ inline double replica_sum(const mfc_stat_t* base, size_t stride) {
+    double p[MFC_R];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[k] = 0.f;
+    for (int r = 0; r < MFC_R; ++r) p[r] = base[(size_t)r * stride];
+    double s = 0.0;
 #pragma unroll
-    for (int r = 0; r < MFC_R; r += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] += base[(size_t)(r + k) * stride];
-    }
-    return ((double)p[0] + (double)p[1]) + ((double)p[2] + (double)p[3]) + ((double)p[4] + (double)p[5]) + ((double)p[6] + (double)p[7]);
+    for (int r = 0; r < MFC_R; ++r) s += p[r];
+    return s;
 }
 
 // block = 64 channels x 4 group slots; grid = ceil(Cp / 64)
@@ -89,7 +87,7 @@ extern "C" int mfc_bn_finalize(const mfc_bnfin_desc* d, void* stream) {
     if (d->training && !d->stats) return MFC_ERR_INVALID_ARG;
     if (d->C <= 0 || d->C > d->Cp || d->G <= 0) return MFC_ERR_INVALID_ARG;
     if (d->G > 8) return MFC_ERR_UNSUPPORTED;
-    if (g_mfc_prof_on == 1) mfc_prof_before((hipStream_t)stream, "bn_finalize_kernel", 0.0, d->training ? (double)MFC_R * d->G * 2 * d->Cp * 4 : 0.0);
+    if (g_mfc_prof_on == 1) mfc_prof_before((hipStream_t)stream, "bn_finalize_kernel", 0.0, d->training ? (double)MFC_R * d->G * 2 * d->Cp * sizeof(mfc_stat_t) : 0.0);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((d->Cp + 63) / 64), dim3(256), 0, (hipStream_t)stream, *d);
     MFC_PROF_END((hipStream_t)stream);
     MFC_CHECK_LAUNCH();
@@ -355,7 +353,7 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
         const int rep = blockIdx.x % MFC_R;
         const int G = gridDim.y;
         const int c = d.y.c_off + g2 * E + (k >> 1);
-        atomicAdd(d.bstats + (((size_t)rep * G + grp) * 2 + (k & 1)) * d.y.Cp + c, red[k * 256 + g2]);
+        atomicAdd(d.bstats + (((size_t)rep * G + grp) * 2 + (k & 1)) * d.y.Cp + c, (mfc_stat_t)red[k * 256 + g2]);
     }
 }
 

@@ -22,7 +22,8 @@ F32, BF16, F16 = 0, 1, 2
 def is16(dtype: int) -> bool:
     """16-bit storage (bf16 or fp16): 8 channels per 16-byte granule, MFMA 16x16x32 kernels."""
     return dtype in (BF16, F16)
-STAT_REPLICAS = 32
+STAT_REPLICAS = 8
+STAT_BYTES = 8            # sizeof(mfc_stat_t): the statistic cells are fp64
 
 # op kinds (mfc_op_kind)
 OP_CONV, OP_WGRAD, OP_BNFIN, OP_COMBINE, OP_BNBWD_REDUCE, OP_BNBWD_FIN, OP_BNBWD_APPLY, OP_MASK_ADD = range(1, 9)

@@ -218,8 +218,8 @@ class Plan:
         C_, Cp = like.C, like.Cp
         R = L.STAT_REPLICAS
         return BN(name, C_, Cp, G, training, float(like.ipg * like.H * like.W),
-                  self._alloc("stats", R * G * 2 * Cp * 4), self._alloc("misc", G * 4 * Cp * 4),
-                  self._alloc("bstats", R * G * 2 * Cp * 4) if self.need_backward else 0,
+                  self._alloc("stats", R * G * 2 * Cp * L.STAT_BYTES), self._alloc("misc", G * 4 * Cp * 4),
+                  self._alloc("bstats", R * G * 2 * Cp * L.STAT_BYTES) if self.need_backward else 0,
                   self._alloc("misc", G * 2 * Cp * 4) if self.need_backward else 0)
 
     def view(self, t: Ten, bn: Optional[BN] = None, c_off=0) -> L.View:

@@ -128,7 +128,7 @@ class _Program:
         r.i[0], r.i[1], r.i[2] = cout, cin * 9, struct.unpack("i", struct.pack("f", WS_EPS))[0]
         self.pro.append((L.OP_WSNORM, r))
         Cp = rup(cout, 8)
-        stats = self._alloc("stats", L.STAT_REPLICAS * x.N * 2 * Cp * 4)
+        stats = self._alloc("stats", L.STAT_REPLICAS * x.N * 2 * Cp * L.STAT_BYTES)
         y = self.conv(x, ws, cout, cin, 3, 1, 1, self.p(name + ".proj.bias"), stats)
         coef = self._alloc("misc", x.N * 4 * Cp * 4)
         self.recs.append((L.OP_GNFIN, L.GnFinDesc(stats, coef, self.p(name + ".norm.weight"), self.p(name + ".norm.bias"), cout, Cp, x.N,

@@ -445,6 +445,23 @@ def test_one_bit_relu_masks_give_the_same_gradients(mfc):
     assert rel_l2(g0.numpy(), g1.numpy()) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_training_forward_is_bit_reproducible(mfc, dtype):
+    """Two training-mode forwards of the same clip give the same bits, with the branch lanes on: the only order-dependent arithmetic of the
+    forward pass, the BatchNorm sum atomics, runs on fp64 cells (mfc_stat_t).  With fp32 cells the bf16 logits of this very case differed
+    by 15 % of their scale between runs (var = E[x^2] - mean^2 amplifies the 1e-7 order noise on low-variance channels of the 3x4-pixel
+    branch; tools/train_noise.py)."""
+    cfg = dict(name="bitscase", model_type="HRNetMulti-Large", T=3, optflow=False, depth=False, B=2, H=96, W=128, mode="train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    m = build(mfc, cfg, dtype=dtype)
+    m.train()
+    ys = [m(dev(frames)).detach().clone() for _ in range(4)]
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
+    m2 = build(mfc, cfg, dtype=dtype)
+    m2.train()
+    assert torch.equal(ys[0], m2(dev(frames)).detach())
+
+
 def test_captured_graph_replays_the_forward_program(mfc):
     """mfc_graph_capture / mfc_graph_launch: the forward program as a hipGraph (lanes become graph branches) writes the
     same logits as mfc_program_run."""

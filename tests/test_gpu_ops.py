@@ -88,7 +88,7 @@ def test_conv_fused_bn_relu_input_and_stats(M, dtype, cfg):
     if dtype in H16:
         xa = xa.to(dtype).float()
     ref = F.conv2d(xa, w, None, padding=k // 2)
-    stats = torch.zeros(L.STAT_REPLICAS, G, 2, Cout, device="cuda")
+    stats = torch.zeros(L.STAT_REPLICAS, G, 2, Cout, dtype=torch.float64, device="cuda")
     y = ops.conv2d(ops.to_nhwc(x, dtype), w.cuda(), k, 1, in_coef=coef.cuda(), in_relu=True, ipg=2, stats=stats)
     out = ops.to_nchw(y, Cout).cpu()
     assert relerr(out, ref) < TOL[dtype]
@@ -111,7 +111,7 @@ def test_conv1x1_bias_and_stats_without_input_transform(M, dtype, cfg):
     w = rnd(dtype, Cout, Cin, 1, 1, seed=15, scale=1.0 / np.sqrt(Cin))
     b = rnd(torch.float32, Cout, seed=16)
     ref = F.conv2d(x, w, b)
-    stats = torch.zeros(L.STAT_REPLICAS, G, 2, ops.rup(Cout, 8), device="cuda")
+    stats = torch.zeros(L.STAT_REPLICAS, G, 2, ops.rup(Cout, 8), dtype=torch.float64, device="cuda")
     y = ops.conv2d(ops.to_nhwc(x, dtype), w.cuda(), 1, 1, bias=b.cuda(), ipg=2, stats=stats)
     assert relerr(ops.to_nchw(y, Cout).cpu(), ref) < TOL[dtype]
     st = stats.sum(0).cpu()
@@ -187,7 +187,7 @@ def test_dgrad_fused_bn_backward_reduce(dt16, M, case):
     dyd, yd, srcd = ops.to_nhwc(dy, dt16), ops.to_nhwc(ybn, dt16), ops.to_nhwc(base, dt16)
     bits = pack_sign_bits(ops.to_nhwc(signsrc, dt16))
     dx = torch.zeros(N, H, W, Cin, dtype=dt16, device="cuda")
-    bstats = torch.zeros(L.STAT_REPLICAS, G, 2, Cin, device="cuda")
+    bstats = torch.zeros(L.STAT_REPLICAS, G, 2, Cin, dtype=torch.float64, device="cuda")
     coef_d = coef.cuda()
     Ho, Wo, pad = yo.shape[2], yo.shape[3], k // 2
     keep, launched = [], 0
@@ -339,7 +339,7 @@ def test_bn_finalize_matches_batch_norm(M):
     rm, rv = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
     rm_ref, rv_ref = rm.clone(), rv.clone()
     outs = [F.batch_norm(y[g * ipg:(g + 1) * ipg], rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5) for g in range(G)]
-    stats = torch.zeros(L.STAT_REPLICAS, G, 2, Cc)
+    stats = torch.zeros(L.STAT_REPLICAS, G, 2, Cc, dtype=torch.float64)
     for g in range(G):
         yy = y[g * ipg:(g + 1) * ipg]
         stats[g % L.STAT_REPLICAS, g, 0] = yy.sum((0, 2, 3))
@@ -424,7 +424,7 @@ def test_bn_backward(M, dtype, mode):
     ty, tg = ops.to_nhwc(y.detach(), dtype), ops.to_nhwc(ga, dtype)
     ta = ops.to_nhwc(a.detach(), dtype)
     coefd = coef.cuda()
-    bst = torch.zeros(L.STAT_REPLICAS, G, 2, Cc, device="cuda")
+    bst = torch.zeros(L.STAT_REPLICAS, G, 2, Cc, dtype=torch.float64, device="cuda")
     bco = torch.zeros(G, 2, Cc, device="cuda")
     dgam, dbet = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
     dy = torch.zeros_like(ty)

@@ -99,7 +99,7 @@ def run_node(ci, L, ops, seed):
     xd = nhwc(x, f.Cin_p)
     d = clone_desc(f)
     out = torch.zeros(N, f.Hout, f.Wout, f.Cout_p, dtype=torch.bfloat16, device="cuda")
-    stats = torch.zeros(L.STAT_REPLICAS, G, 2, f.Cout_p, device="cuda") if f.out_stats else None
+    stats = torch.zeros(L.STAT_REPLICAS, G, 2, f.Cout_p, dtype=torch.float64, device="cuda") if f.out_stats else None
     coef_d = coef.cuda() if coef is not None else None
     bias_d = bias.cuda() if bias is not None else None
     d.inp, d.out = xd.data_ptr(), out.data_ptr()
@@ -146,7 +146,7 @@ def run_node(ci, L, ops, seed):
             yd2, cf2d = nhwc(ybn, f.Cin_p), cf2.cuda()
             sgn = nhwc(signsrc, f.Cin_p)
             bits = ((sgn.float() > 0).to(torch.int32).reshape(-1, 8) * torch.tensor([1 << e for e in range(8)], dtype=torch.int32, device="cuda")).sum(1).to(torch.uint8).contiguous()
-            bst = torch.zeros(L.STAT_REPLICAS, G, 2, f.Cin_p, device="cuda")
+            bst = torch.zeros(L.STAT_REPLICAS, G, 2, f.Cin_p, dtype=torch.float64, device="cuda")
         keep = []
         for dg in ci.dgrad:
             q = clone_desc(dg)

@@ -12,7 +12,7 @@ for (N, Cin, Cout, k, H, W) in [(24, 32, 32, 3, 120, 160), (24, 48, 48, 3, 120, 
         x = torch.randn(N, H, W, ops.rup(Cin, 8), device="cuda").to(torch.bfloat16)
         w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
         out = torch.zeros(N, H, W, ops.rup(Cout, 8), dtype=torch.bfloat16, device="cuda")
-        stats = torch.zeros(L.STAT_REPLICAS, 3, 2, out.shape[3], device="cuda")
+        stats = torch.zeros(L.STAT_REPLICAS, 3, 2, out.shape[3], dtype=torch.float64, device="cuda")
         coef = torch.rand(3, 4, x.shape[3], device="cuda")
         line = f"{(N,Cin,Cout,k,H,W)} xf={xf}"
         for grid in (512, 768, 1024):

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd /root/repo
+one() { python bench.py "$@" --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; }
+for rep in 1 2; do
+for R in 32 16 8; do
+  cp mfcnet-tracker_amd/csrc/build/variants/libR$R.so mfcnet-tracker_amd/mfcnet_amd/libmfcnet_hip.so
+  sed -i "s/^STAT_REPLICAS = [0-9]*/STAT_REPLICAS = $R/" mfcnet-tracker_amd/mfcnet_amd/_lib.py
+  echo "R=$R  W32 B8: $(one --steps 20 --warmup 5)  b=1: $(one --batch 1 --steps 30 --warmup 5)  W48: $(one --width 48 --steps 10 --warmup 3)"
+done
+done

@@ -35,7 +35,7 @@ def main():
         x = torch.randn(N, H, W, ops.rup(Cin, 8), device="cuda").to(dt)
         w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
         out = torch.zeros(N, Ho, Wo, ops.rup(Cout, 8), dtype=dt, device="cuda")
-        stats = torch.zeros(L.STAT_REPLICAS, 3, 2, out.shape[3], device="cuda")
+        stats = torch.zeros(L.STAT_REPLICAS, 3, 2, out.shape[3], dtype=torch.float64, device="cuda")
         coef = torch.rand(3, 4, x.shape[3], device="cuda")
         flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         line = f"{str((N,Cin,Cout,k,s,H,W)):38s}"

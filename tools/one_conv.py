@@ -13,7 +13,7 @@ Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
 x = torch.randn(N, H, W, ops.rup(Cin, 8), device="cuda").to(dt)
 w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
 out = torch.zeros(N, Ho, Wo, ops.rup(Cout, 8), dtype=dt, device="cuda")
-stats = torch.zeros(L.STAT_REPLICAS, 3, 2, out.shape[3], device="cuda")
+stats = torch.zeros(L.STAT_REPLICAS, 3, 2, out.shape[3], dtype=torch.float64, device="cuda")
 coef = torch.rand(3, 4, x.shape[3], device="cuda")
 d = L.ConvDesc(x.data_ptr(), 0, out.data_ptr(), 0, coef.data_ptr() if fused else 0, stats.data_ptr() if fused else 0,
                ops.dt_of(x), N, H, W, x.shape[3], Cin, Ho, Wo, out.shape[3], Cout, Ho, Wo, k, k, -pad, -pad, s, 1, 1, 0, 0, 1, N // 3, 0, 0, 0)
