@@ -1,4 +1,5 @@
 #!/bin/bash
+# A/B of MFC_STAT_REPLICAS on one box: expects mfcnet-tracker_amd/csrc/build/variants/libR<n>.so (build each with the header constant set to n)
 cd /root/repo
 one() { python bench.py "$@" --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; }
 for rep in 1 2; do
