@@ -45,15 +45,21 @@ def test_ctypes_mirrors_match_c_struct_sizes(L):
                "mfc_headgather_desc": L.HeadDesc, "mfc_loss_desc": L.LossDesc, "mfc_conv_layout": L.ConvLayout,
                "mfc_prof_entry": L.ProfEntry}
     prog = '#include "mfcnet_hip.h"\n#include <stdio.h>\nint main(){' + "".join(
-        f'printf("{n} %zu\\n", sizeof({n}));' for n in structs) + "return 0;}"
+        f'printf("{n} %zu\\n", sizeof({n}));' for n in structs) + \
+        'printf("STAT_REPLICAS %d\\nSTAT_BYTES %zu\\nF16 %d\\n", MFC_STAT_REPLICAS, sizeof(mfc_stat_t), (int)MFC_F16);return 0;}'
     with tempfile.TemporaryDirectory() as td:
         src, exe = os.path.join(td, "s.c"), os.path.join(td, "s")
         open(src, "w").write(prog)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    consts = {"STAT_REPLICAS": L.STAT_REPLICAS, "STAT_BYTES": L.STAT_BYTES, "F16": L.F16}      # constants the Python side mirrors
     for line in out.strip().splitlines():
         name, size = line.split()
-        assert C.sizeof(structs[name]) == int(size), name
+        if name in consts:
+            assert consts.pop(name) == int(size), name
+        else:
+            assert C.sizeof(structs[name]) == int(size), name
+    assert not consts
     assert L.lib.mfc_op_size() == C.sizeof(L.Op)
 
 
