@@ -55,6 +55,7 @@ typedef enum {
  * atomics (1e-7 relative) is amplified by var = E[x^2] - mean^2 on channels whose variance is small against their mean, and a bf16 training-mode
  * forward then has run-to-run differences of 15 % of the logit scale at low resolutions (tools/train_noise.py); with fp64 cells it repeats. */
 typedef double mfc_stat_t;
+#define MFC_LOSS_ACC_FLOATS 96
 
 /* ---- BatchNorm coefficient block: fp32 [G][4][Cp] = scale, shift, mean, rstd ---- */
 #define MFC_COEF_SCALE 0
@@ -356,7 +357,9 @@ int mfc_head_gather_bwd(const mfc_headgather_desc* d, void* dlogits, void* strea
 
 /* ------------------------------------------------------------------------------------
  * Loss: F.log_softmax(dim=1) + class-weighted NLL + soft-Jaccard, forward and gradient
- * wrt logits (src/engine.py:65-66, src/loss.py:31-63).  acc: fp32[32]:
+ * wrt logits (src/engine.py:65-66, src/loss.py:31-63).  acc: DEVICE fp32[MFC_LOSS_ACC_FLOATS], 8-byte aligned; [0..31] hold the results
+ * below, [32..95] are scratch of mfc_loss_partial (the 26 sums as fp64 cells, so that the totals do not depend on the order the workgroups add
+ * in; mfc_loss_finalize and mfc_loss_bwd read [0..31] only):
  *   [0] sum w_t*(-logp_t)  [1] sum w_t  [2+c] I_c = sum p_c*[t==c]  [10+c] sum p_c  [18+c] sum [t==c]   (c < 8)
  *   [26] nll  [27] soft-jaccard  [28] w_nll*nll + w_jac*jaccard
  *   [29] number of targets outside [0, nc): such pixels contribute nothing to the NLL term (and count as "no class" in the Jaccard

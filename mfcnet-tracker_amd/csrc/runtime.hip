@@ -7,10 +7,11 @@
 
 // acc layout: [0] sum w_t*(-logp_t)  [1] sum w_t  [2+c] I_c  [10+c] P_c = sum p_c  [18+c] T_c = sum [t==c]
 //             [26] nll  [27] soft-jaccard  [28] total  [29] number of targets outside [0, nc) (they are ignored; nn.NLLLoss raises on them)
+// The 26 sums are order-independent: lanes -> wave (shuffles) -> workgroup (fixed order over the 4 waves) in fp32, workgroups -> total
+// with fp64 atomics into the scratch half of the acc block; loss_sums_kernel then rounds the totals to acc[0..25].
 __global__ __launch_bounds__(256) void loss_fwd_kernel(mfc_loss_desc d, long total) {
-    __shared__ float red[26];
+    __shared__ float wred[4][26];
     __shared__ unsigned bad_s;
-    if (threadIdx.x < 26) red[threadIdx.x] = 0.f;
     if (threadIdx.x == 0) bad_s = 0u;
     __syncthreads();
     const long HW = (long)d.H * d.W;
@@ -47,13 +48,21 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(mfc_loss_desc d, long tot
         for (int c = 1; c < d.nc; ++c) { I[c] += __shfl_down(I[c], off); P[c] += __shfl_down(P[c], off); Tc[c] += __shfl_down(Tc[c], off); }
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&red[0], a0); atomicAdd(&red[1], a1);
-        for (int c = 1; c < d.nc; ++c) { atomicAdd(&red[2 + c], I[c]); atomicAdd(&red[10 + c], P[c]); atomicAdd(&red[18 + c], Tc[c]); }
+        float* r = wred[threadIdx.x >> 6];
+        for (int i = 0; i < 26; ++i) r[i] = 0.f;
+        r[0] = a0; r[1] = a1;
+        for (int c = 1; c < d.nc; ++c) { r[2 + c] = I[c]; r[10 + c] = P[c]; r[18 + c] = Tc[c]; }
     }
     if (bad) atomicAdd(&bad_s, bad);
     __syncthreads();
-    if (threadIdx.x < 26 && red[threadIdx.x] != 0.f) atomicAdd(d.acc + threadIdx.x, red[threadIdx.x]);
-    if (threadIdx.x == 0 && bad_s) atomicAdd(d.acc + 29, (float)bad_s);
+    if (threadIdx.x < 26) {
+        const float v = ((wred[0][threadIdx.x] + wred[1][threadIdx.x]) + wred[2][threadIdx.x]) + wred[3][threadIdx.x];
+        if (v != 0.f) atomicAdd((double*)(d.acc + 32) + threadIdx.x, (double)v);
+    }
+    if (threadIdx.x == 0 && bad_s) atomicAdd(d.acc + 29, (float)bad_s);       // (a count: exact in fp32 whatever the order)
+}
+__global__ void loss_sums_kernel(mfc_loss_desc d) {
+    if (threadIdx.x < 26) d.acc[threadIdx.x] = (float)((const double*)(d.acc + 32))[threadIdx.x];
 }
 
 __global__ void loss_finalize_kernel(mfc_loss_desc d) {
@@ -77,10 +86,12 @@ static int loss_check(const mfc_loss_desc* d) {
 extern "C" int mfc_loss_partial(const mfc_loss_desc* d, void* stream) {
     int rc = loss_check(d); if (rc < 0) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(d->acc, 0, 32 * sizeof(float), st) != hipSuccess) return MFC_ERR_LAUNCH;
+    if (((uintptr_t)d->acc) & 7) return MFC_ERR_INVALID_ARG;
+    if (hipMemsetAsync(d->acc, 0, MFC_LOSS_ACC_FLOATS * sizeof(float), st) != hipSuccess) return MFC_ERR_LAUNCH;
     const long total = (long)d->B * d->H * d->W;
     long blocks = (total + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(loss_fwd_kernel, dim3((int)blocks), dim3(256), 0, st, *d, total);
+    hipLaunchKernelGGL(loss_sums_kernel, dim3(1), dim3(64), 0, st, *d);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

@@ -24,6 +24,7 @@ def is16(dtype: int) -> bool:
     return dtype in (BF16, F16)
 STAT_REPLICAS = 8
 STAT_BYTES = 8            # sizeof(mfc_stat_t): the statistic cells are fp64
+LOSS_ACC_FLOATS = 96      # MFC_LOSS_ACC_FLOATS: 32 result floats + the scratch of mfc_loss_partial
 
 # op kinds (mfc_op_kind)
 OP_CONV, OP_WGRAD, OP_BNFIN, OP_COMBINE, OP_BNBWD_REDUCE, OP_BNBWD_FIN, OP_BNBWD_APPLY, OP_MASK_ADD = range(1, 9)

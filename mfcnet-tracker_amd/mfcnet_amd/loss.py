@@ -24,7 +24,7 @@ class _LossFn(torch.autograd.Function):
         logits = logits.contiguous().float()
         target = target.contiguous()
         B, nc, H, W = logits.shape
-        acc = torch.empty(32, dtype=torch.float32, device=logits.device)
+        acc = torch.empty(L.LOSS_ACC_FLOATS, dtype=torch.float32, device=logits.device)[:32]     # (the view keeps the whole block alive; [32:] is kernel scratch)
         d = L.LossDesc(logits.data_ptr(), target.data_ptr(), class_w.data_ptr(), acc.data_ptr(), 0, B, nc, H, W, w_nll, w_jac, 1.0)
         if group is None:
             L.call(L.lib.mfc_loss_fwd, d)

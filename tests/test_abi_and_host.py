@@ -46,13 +46,13 @@ def test_ctypes_mirrors_match_c_struct_sizes(L):
                "mfc_prof_entry": L.ProfEntry}
     prog = '#include "mfcnet_hip.h"\n#include <stdio.h>\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in structs) + \
-        'printf("STAT_REPLICAS %d\\nSTAT_BYTES %zu\\nF16 %d\\n", MFC_STAT_REPLICAS, sizeof(mfc_stat_t), (int)MFC_F16);return 0;}'
+        'printf("STAT_REPLICAS %d\\nSTAT_BYTES %zu\\nF16 %d\\nLOSS_ACC_FLOATS %d\\n", MFC_STAT_REPLICAS, sizeof(mfc_stat_t), (int)MFC_F16, MFC_LOSS_ACC_FLOATS);return 0;}'
     with tempfile.TemporaryDirectory() as td:
         src, exe = os.path.join(td, "s.c"), os.path.join(td, "s")
         open(src, "w").write(prog)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    consts = {"STAT_REPLICAS": L.STAT_REPLICAS, "STAT_BYTES": L.STAT_BYTES, "F16": L.F16}      # constants the Python side mirrors
+    consts = {"STAT_REPLICAS": L.STAT_REPLICAS, "STAT_BYTES": L.STAT_BYTES, "F16": L.F16, "LOSS_ACC_FLOATS": L.LOSS_ACC_FLOATS}      # constants the Python side mirrors
     for line in out.strip().splitlines():
         name, size = line.split()
         if name in consts:
