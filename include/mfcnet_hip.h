@@ -325,6 +325,10 @@ int mfc_mask_add(const mfc_maskadd_desc* d, void* stream);
 
 /* per-channel sum over pixels of dy (bias gradient of last_layer.0 / last_layer.3, hrnet.py:335-350) */
 int mfc_bias_grad(const void* dy, float* db, int32_t dtype, int64_t npix, int32_t Cp, int32_t C, void* stream);
+/* the same without atomics: `nparts` workgroups each write the partial sums of their pixel range to slices[part][Cp] (fp32); the caller adds the
+ * slices in a fixed order -- the plan does it with an mfc_unpack_job {KH = KW = 1, Cin = Ci16 = 1, Co16 = Cp}, next to the weight gradients' slices --
+ * so that the bias gradient, like every other gradient, does not depend on the order workgroups finish in (MFC_OP_BIAS_GRAD with raw.i[3] = nparts) */
+int mfc_bias_grad_slices(const void* dy, float* slices, int32_t dtype, int64_t npix, int32_t Cp, int32_t C, int32_t nparts, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Layout bridges at the boundary (the reference API is NCHW fp32 lists of tensors,

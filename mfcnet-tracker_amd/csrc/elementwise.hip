@@ -830,7 +830,9 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
 
 // ------------------------------------------------------------------ bias gradient
 // db[c] += sum over pixels of dy[pix][c]   (db must be zero at step start)
-template <typename T>
+// SLICES: no atomics -- workgroup x writes its partial sums to db[x * Cp + c] (every channel, zeros included); the caller adds the slices up
+// in a fixed order (mfc_unpack_wgrad), so the result does not depend on the order the workgroups finish in
+template <typename T, bool SLICES>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const T* dy, float* db, long npix, int Cp, int C, int Cg, int PPI, int pix_per_block) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 4;                       // granules in flight per thread
@@ -869,7 +871,8 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* dy, float* db, 
         for (int e = 0; e < E; ++e) {
             float a = 0.f;
             for (int q = 0; q < PPI; ++q) a += red[(q * Cg + gi) * E + e];
-            if (ch + e < C) atomicAdd(db + ch + e, a);
+            if (SLICES) db[(size_t)blockIdx.x * Cp + ch + e] = (ch + e < C) ? a : 0.f;
+            else if (ch + e < C) atomicAdd(db + ch + e, a);
         }
     }
 }
@@ -889,7 +892,25 @@ extern "C" int mfc_bias_grad(const void* dy, float* db, int32_t dtype, int64_t n
     ppb = ((ppb + PPI - 1) / PPI) * PPI;
     const int blocks = (int)((npix + ppb - 1) / ppb);
     EW_PROF(st, "bias_grad_kernel", dtype, (double)npix * Cp * (E == 8 ? 2 : 4));
-    MFC_TYPED(dtype, T_, hipLaunchKernelGGL(bias_grad_kernel<T_>, dim3(blocks, nslab), dim3(Cg * PPI), 0, st, (const T_*)dy, db, (long)npix, Cp, C, Cg, PPI, ppb));
+    MFC_TYPED(dtype, T_, hipLaunchKernelGGL((bias_grad_kernel<T_, false>), dim3(blocks, nslab), dim3(Cg * PPI), 0, st, (const T_*)dy, db, (long)npix, Cp, C, Cg, PPI, ppb));
+    MFC_PROF_END(st);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+extern "C" int mfc_bias_grad_slices(const void* dy, float* slices, int32_t dtype, int64_t npix, int32_t Cp, int32_t C, int32_t nparts, void* stream) {
+    if (!dy || !slices || npix <= 0 || Cp <= 0 || C > Cp || Cp % 8 || nparts <= 0 || nparts > 4096) return MFC_ERR_INVALID_ARG;
+    if (!mfc_dtype_ok(dtype)) return MFC_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int E = mfc_is16(dtype) ? 8 : 4;
+    const int Cgt = Cp / E;
+    const int nslab = (Cgt + 15) / 16;
+    const int Cg = (Cgt + nslab - 1) / nslab;
+    const int PPI = 256 / Cg;
+    int ppb = (int)((npix + nparts - 1) / nparts);
+    ppb = ((ppb + PPI - 1) / PPI) * PPI;            // (workgroups past the last pixel write zero slices)
+    EW_PROF(st, "bias_grad_kernel", dtype, (double)npix * Cp * (E == 8 ? 2 : 4));
+    MFC_TYPED(dtype, T_, hipLaunchKernelGGL((bias_grad_kernel<T_, true>), dim3(nparts, nslab), dim3(Cg * PPI), 0, st, (const T_*)dy, slices, (long)npix, Cp, C, Cg, PPI, ppb));
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;

@@ -369,7 +369,9 @@ static int run_one(const mfc_op& o, void* stream) {
         case MFC_OP_MASK_ADD: return mfc_mask_add(&o.u.maskadd, stream);
         case MFC_OP_HEAD_FWD: return mfc_head_gather_fwd(&o.u.head, stream);
         case MFC_OP_HEAD_BWD: return mfc_head_gather_bwd(&o.u.headbwd.d, (void*)o.u.headbwd.dlogits, stream);
-        case MFC_OP_BIAS_GRAD:   // a = dy, b = db, n = npix, i[0]=dtype, i[1]=Cp, i[2]=C
+        case MFC_OP_BIAS_GRAD:   // a = dy, b = db (or, with i[3] = nparts > 0, the slices), n = npix, i[0]=dtype, i[1]=Cp, i[2]=C
+            if (o.u.raw.i[3] > 0)
+                return mfc_bias_grad_slices((const void*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.n, o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3], stream);
             return mfc_bias_grad((const void*)o.u.raw.a, (float*)o.u.raw.b, o.u.raw.i[0], o.u.raw.n, o.u.raw.i[1], o.u.raw.i[2], stream);
         case MFC_OP_MEMSET:      // a = ptr, n = bytes
             return hipMemsetAsync((void*)o.u.raw.a, 0, (size_t)o.u.raw.n, st) == hipSuccess ? MFC_OK : MFC_ERR_LAUNCH;

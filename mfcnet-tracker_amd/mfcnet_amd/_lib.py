@@ -148,7 +148,7 @@ class Op(C.Structure):
 # every symbol include/mfcnet_hip.h declares
 EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_conv2d_wgrad_parts", "mfc_conv2d_wgrad_batch", "mfc_unpack_wgrad",
            "mfc_bn_finalize", "mfc_bn_finalize_batch", "mfc_ws_normalize", "mfc_gn_finalize", "mfc_upsample_nearest2x", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
-           "mfc_mask_add", "mfc_bias_grad", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
+           "mfc_mask_add", "mfc_bias_grad", "mfc_bias_grad_slices", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd", "mfc_confusion_counts", "mfc_adam_step", "mfc_adam_step_guarded", "mfc_grad_check", "mfc_program_run", "mfc_program_run_ex", "mfc_wait_detached", "mfc_program_profile", "mfc_graph_capture", "mfc_graph_launch", "mfc_graph_destroy",
            "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect", "mfc_prof_dump"]
 
@@ -177,6 +177,7 @@ def _load():
     lib.mfc_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
     lib.mfc_graph_destroy.argtypes = [C.c_void_p]
     lib.mfc_bias_grad.argtypes = [vp, vp, i32, C.c_int64, i32, i32, vp]
+    lib.mfc_bias_grad_slices.argtypes = [vp, vp, i32, C.c_int64, i32, i32, i32, vp]
     lib.mfc_nchw_to_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.mfc_nhwc_to_nchw.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.mfc_pack_weights.argtypes = [vp, i32, i32, i32, vp]

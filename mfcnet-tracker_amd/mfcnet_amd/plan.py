@@ -28,6 +28,7 @@ from . import _lib as L
 from .arch import branch_widths, head_in_channels
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1          # nn.BatchNorm defaults; hrnet.py:34
+BIAS_PARTS = 64                           # partial-sum slices of a bias gradient (one per workgroup of mfc_bias_grad_slices)
 
 
 def rup(x, m):
@@ -716,9 +717,15 @@ class Plan:
                 ci.wg.x, ci.wg.dy = xt.ptr, dy.ptr
                 self._queue_wgrad(ci)
                 if ci.bias:
-                    r = L.RawOp(dy.ptr, self.gptr(ci.bias), 0, y.N * y.H * y.W)
-                    r.i[0:3] = [self.dtype, y.Cp, ci.cout]
+                    # partial sums per workgroup (no atomics), added up in a fixed order by the unpack launch of the bucket, like the weight
+                    # gradients' slices: the gradient arena is the same, bit for bit, whatever order the workgroups finish in
+                    NP = BIAS_PARTS
+                    sl = self._alloc("dwp", NP * y.Cp * 4)
+                    r = L.RawOp(dy.ptr, sl, 0, y.N * y.H * y.W)
+                    r.i[0:4] = [self.dtype, y.Cp, ci.cout, NP]
                     self.bwd.append((L.OP_BIAS_GRAD, r))
+                    self.unpack_jobs.append(dict(src=sl, nparts=NP, dst=self.gptr(ci.bias), Cout=ci.cout, Cin=1, KH=1, KW=1, Co16=y.Cp, Ci16=1,
+                                                 _name=ci.bias))
                     self._grad_ready(ci.bias)
                 if xt.needs_grad:
                     dx = self.grad_of(xt)
@@ -872,6 +879,8 @@ class Plan:
             elif rec[0] == L.OP_WGRAD_BATCH:
                 cursor += rec[1].i[0]; nwg += 1
             else:
+                if rec[0] == L.OP_BIAS_GRAD and rec[1].i[3] > 0:
+                    cursor += 1                                  # (its partial-sum slices ride in the next unpack)
                 continue
             if chunk > 0 and nwg % chunk == 0:
                 flush(rec[2] & 0xff)

@@ -159,7 +159,8 @@ def test_gradient_buckets_partition_the_backward_program():
         for i in range(len(prog)):
             if prog[i].kind == L.OP_UNPACK:
                 n_unpack += prog[i].u.raw.i[0]
-    assert n_unpack == len(pl.unpack_jobs) == 311
+    n_bias = sum(1 for o in one if o.kind == L.OP_BIAS_GRAD and o.u.raw.i[3] > 0)      # bias gradients are partial-sum slices too
+    assert n_unpack == len(pl.unpack_jobs) == 311 + n_bias and n_bias == 2
     # buckets complete from the end of the arena (the head is first in backward)
     assert pl.bwd_segments[0][2] == m._np
 

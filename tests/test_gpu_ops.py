@@ -716,6 +716,29 @@ def test_wgrad_batch_matches_single_launches(M):
     assert L.lib.mfc_conv2d_wgrad_batch(descs, n, L.stream_ptr()) == -1
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(3, 5, 37, 41), (2, 480, 24, 40), (1, 72, 7, 9)])
+def test_bias_grad_atomics_and_slices(M, dtype, case):
+    """mfc_bias_grad (fp32 atomics into db) and mfc_bias_grad_slices (per-workgroup partial sums, summed by the caller in a fixed order -- the
+    form the plan uses, so that the gradient arena repeats bit for bit): both equal the per-channel sum over pixels; the slices repeat exactly."""
+    _, L, ops = M
+    N, Cc, H, W = case
+    dy = rnd(dtype, N, Cc, H, W, seed=81)
+    ref = dy.sum((0, 2, 3))
+    dyd = ops.to_nhwc(dy, dtype)
+    Cp = dyd.shape[3]
+    db = torch.zeros(Cc, device="cuda")
+    L.check(L.lib.mfc_bias_grad(dyd.data_ptr(), db.data_ptr(), ops.dt_of(dyd), N * H * W, Cp, Cc, L.stream_ptr()), "bias_grad")
+    assert relerr(db.cpu(), ref) < 1e-5
+    outs = []
+    for _ in range(2):
+        sl = torch.full((16, Cp), float("nan"), device="cuda")
+        L.check(L.lib.mfc_bias_grad_slices(dyd.data_ptr(), sl.data_ptr(), ops.dt_of(dyd), N * H * W, Cp, Cc, 16, L.stream_ptr()), "bias_grad_slices")
+        outs.append(sl.clone())
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+    assert relerr(outs[0].sum(0)[:Cc].cpu(), ref) < 1e-5 and float(outs[0][:, Cc:].abs().max() if Cp > Cc else 0.0) == 0.0
+
+
 def test_guarded_adam_skips_a_step_with_non_finite_gradients(M):
     """mfc_grad_check + mfc_adam_step_guarded (the overflow guard of a loss-scaled fp16 step): finite gradients -> the same update as
     mfc_adam_step, bit for bit; one Inf or NaN anywhere in the arena -> parameters and both moments untouched, counter incremented."""
