@@ -12,6 +12,11 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU references (oracle, F.conv2d + autograd) run on the host: torch's default of one thread per logical CPU (128 on the GPU box's
+    # 256-thread EPYC) is 1.6x SLOWER than 32 threads for these sizes (measured: tests/test_gpu_plan_kernels.py 69 s vs 41 s)
+    import torch
+    if torch.get_num_threads() > 32:
+        torch.set_num_threads(32)
 
 
 @pytest.fixture(scope="session")
