@@ -1,4 +1,5 @@
-"""The launches the BENCHMARKED plan actually makes (BASELINE.json configs[2]: T=3, B=8, 480x640, bf16; HRNet-w32 and -w48): every
+"""The launches the BENCHMARKED plans actually make (BASELINE.json configs[2]: T=3, B=8, 480x640, bf16, HRNet-w32 and -w48; and the per-GPU
+share of configs[4]: T=5, B=8, 720x960, fp16, W48): every
 distinct convolution node of that plan -- forward launch, data-gradient launch(es) and weight-gradient launch, with the plan's own
 descriptors (so the geometry the library's search picks for N = 24 images at 120x160 ... 15x20, persistent ranges, XCD remap,
 8-wave forms, split-K slices) -- is run once on seeded tensors and compared with PyTorch's CPU fp32 operators (F.conv2d + autograd)
@@ -14,7 +15,8 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-TOL = 1.5e-2
+TOL = 1.5e-2                     # bf16; set per case by the test (fp16: 2e-3)
+DT16 = torch.bfloat16            # 16-bit storage type of the case being run
 
 
 def relerr(a, b):
@@ -22,7 +24,8 @@ def relerr(a, b):
 
 
 def bf(t):
-    return t.bfloat16().float()
+    """round to the 16-bit storage type of the case (bf16 or fp16)"""
+    return t.to(DT16).float()
 
 
 GEOM = ("dtype", "N", "Hin", "Win", "Cin_p", "Cin", "Hout", "Wout", "Cout_p", "Cout", "Hl", "Wl", "TA", "TB", "dh0", "dw0", "in_stride",
@@ -42,10 +45,10 @@ def node_key(ci):
     return (conv_key(ci.fwd), tuple(conv_key(d) for d in ci.dgrad), _fields(g, 4) + (bool(g.in_coef),))
 
 
-def unique_nodes(width, B=8, H=480, W=640, T=3):
+def unique_nodes(width, B=8, H=480, W=640, T=3, dtype="bf16"):
     import mfcnet_amd as mfc
     from mfcnet_amd.plan import Plan
-    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=T, pretrained=False, width=width, compute_dtype="bf16").train()
+    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=T, pretrained=False, width=width, compute_dtype=dtype).train()
     pl = Plan(m, B, H, W, False, False, True, True, True, torch.device("cpu"), dry=True)
     seen = {}
     for op in pl.ops:
@@ -61,10 +64,10 @@ def clone_desc(d):
 
 
 def nhwc(t_nchw, Cp):
-    """CPU fp32 NCHW (already bf16-rounded) -> device bf16 NHWC with zero channel padding"""
+    """CPU fp32 NCHW (already rounded to the storage type) -> device 16-bit NHWC with zero channel padding"""
     N, Cc, H, W = t_nchw.shape
-    out = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16)
-    out[..., :Cc] = t_nchw.permute(0, 2, 3, 1).bfloat16()
+    out = torch.zeros(N, H, W, Cp, dtype=DT16)
+    out[..., :Cc] = t_nchw.permute(0, 2, 3, 1).to(DT16)
     return out.cuda()
 
 
@@ -98,7 +101,7 @@ def run_node(ci, L, ops, seed):
     # ---- forward launch, the plan's descriptor with test tensors
     xd = nhwc(x, f.Cin_p)
     d = clone_desc(f)
-    out = torch.zeros(N, f.Hout, f.Wout, f.Cout_p, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(N, f.Hout, f.Wout, f.Cout_p, dtype=DT16, device="cuda")
     stats = torch.zeros(L.STAT_REPLICAS, G, 2, f.Cout_p, dtype=torch.float64, device="cuda") if f.out_stats else None
     coef_d = coef.cuda() if coef is not None else None
     bias_d = bias.cuda() if bias is not None else None
@@ -183,15 +186,22 @@ def run_node(ci, L, ops, seed):
     return what
 
 
-@pytest.mark.parametrize("width", [32, 48])
-def test_every_conv_node_of_the_benchmarked_plan(width):
+CASES = [(32, "bf16", 8, 480, 640, 3),          # BASELINE.json configs[2] (the metric's model)
+         (48, "bf16", 8, 480, 640, 3),          # the same with the reference's widths
+         (48, "fp16", 8, 720, 960, 5)]          # the per-GPU share of configs[4]: T=5, 720x960, fp16 (N = 40 images per launch)
+
+
+@pytest.mark.parametrize("width,dtype,B,H,W,T", CASES, ids=["w32-bf16-480x640", "w48-bf16-480x640", "w48-fp16-t5-720x960"])
+def test_every_conv_node_of_the_benchmarked_plan(width, dtype, B, H, W, T):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from mfcnet_amd import _lib as L, ops
-    nodes = unique_nodes(width)
+    global DT16, TOL
+    DT16, TOL = (torch.float16, 2e-3) if dtype == "fp16" else (torch.bfloat16, 1.5e-2)
+    nodes = unique_nodes(width, B, H, W, T, dtype)
     assert 30 <= len(nodes) <= 80
     done = [run_node(ci, L, ops, 100 + i) for i, ci in enumerate(nodes)]
     nfused = sum(1 for ci in nodes if ci.dgrad and ci.dgrad[0].bn_y)
     assert nfused >= (10 if width == 32 else 4)          # the fused data-gradient epilogues of the plan are among them
     print(f"w{width}: {len(done)} distinct convolution nodes (fwd + dgrad + wgrad; {nfused} with a fused BatchNorm-backward epilogue) "
-          f"of the B=8 480x640 bf16 plan match CPU fp32")
+          f"of the B={B} T={T} {H}x{W} {dtype} plan match CPU fp32")
