@@ -45,11 +45,12 @@ def node_key(ci):
     return (conv_key(ci.fwd), tuple(conv_key(d) for d in ci.dgrad), _fields(g, 4) + (bool(g.in_coef),))
 
 
-def unique_nodes(width, B=8, H=480, W=640, T=3, dtype="bf16"):
+def unique_nodes(width, B=8, H=480, W=640, T=3, dtype="bf16", aux=False):
     import mfcnet_amd as mfc
     from mfcnet_amd.plan import Plan
-    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=T, pretrained=False, width=width, compute_dtype=dtype).train()
-    pl = Plan(m, B, H, W, False, False, True, True, True, torch.device("cpu"), dry=True)
+    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=T, pretrained=False, width=width, compute_dtype=dtype, optflow_inputs=aux,
+                            depth_inputs=aux).train()
+    pl = Plan(m, B, H, W, aux, aux, True, True, True, torch.device("cpu"), dry=True)
     seen = {}
     for op in pl.ops:
         if op[0] == "conv":
@@ -186,19 +187,20 @@ def run_node(ci, L, ops, seed):
     return what
 
 
-CASES = [(32, "bf16", 8, 480, 640, 3),          # BASELINE.json configs[2] (the metric's model)
-         (48, "bf16", 8, 480, 640, 3),          # the same with the reference's widths
-         (48, "fp16", 8, 720, 960, 5)]          # the per-GPU share of configs[4]: T=5, 720x960, fp16 (N = 40 images per launch)
+CASES = [(32, "bf16", 8, 480, 640, 3, False),          # BASELINE.json configs[2] (the metric's model)
+         (48, "bf16", 8, 480, 640, 3, False),          # the same with the reference's widths
+         (32, "bf16", 4, 480, 640, 3, True),           # the per-GPU share of configs[3]: B=4, depth + optical-flow inputs (N = 12: other geometries)
+         (48, "fp16", 8, 720, 960, 5, False)]          # the per-GPU share of configs[4]: T=5, 720x960, fp16 (N = 40 images per launch)
 
 
-@pytest.mark.parametrize("width,dtype,B,H,W,T", CASES, ids=["w32-bf16-480x640", "w48-bf16-480x640", "w48-fp16-t5-720x960"])
-def test_every_conv_node_of_the_benchmarked_plan(width, dtype, B, H, W, T):
+@pytest.mark.parametrize("width,dtype,B,H,W,T,aux", CASES, ids=["w32-bf16-480x640", "w48-bf16-480x640", "w32-bf16-b4-flow-depth", "w48-fp16-t5-720x960"])
+def test_every_conv_node_of_the_benchmarked_plan(width, dtype, B, H, W, T, aux):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from mfcnet_amd import _lib as L, ops
     global DT16, TOL
     DT16, TOL = (torch.float16, 2e-3) if dtype == "fp16" else (torch.bfloat16, 1.5e-2)
-    nodes = unique_nodes(width, B, H, W, T, dtype)
+    nodes = unique_nodes(width, B, H, W, T, dtype, aux)
     assert 30 <= len(nodes) <= 80
     done = [run_node(ci, L, ops, 100 + i) for i, ci in enumerate(nodes)]
     nfused = sum(1 for ci in nodes if ci.dgrad and ci.dgrad[0].bn_y)
