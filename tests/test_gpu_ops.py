@@ -514,11 +514,15 @@ def test_mask_add_adjoint_bilinear(M, dtype, hw):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("flow,depth", [(False, False), (True, True), (False, True)])
-def test_head_gather_fwd_bwd(M, dtype, flow, depth):
-    """x4 up-sample + temporal concat (hrnet.py:473-474, multiframe_model.py:459-469) and its adjoint."""
+@pytest.mark.parametrize("flow,depth,shape", [(False, False, (2, 3, 12, 20)), (True, True, (2, 3, 12, 20)), (False, True, (2, 3, 12, 20)),
+                                              (False, False, (8, 3, 120, 160)), (True, True, (4, 3, 120, 160)), (False, False, (1, 5, 180, 240))],
+                         ids=["rgb", "flow+depth", "depth", "bench-b8-480x640", "cfg3-b4-480x640-flow+depth", "cfg4-t5-720x960"])
+def test_head_gather_fwd_bwd(M, dtype, flow, depth, shape):
+    """x4 up-sample + temporal concat (hrnet.py:473-474, multiframe_model.py:459-469) and its adjoint -- toy shapes and the launches of the
+    benchmarked configurations (BASELINE.json configs[2], [3], [4])."""
     _, L, ops = M
-    B, T, nc, Hs, Ws = 2, 3, 5, 12, 20
+    B, T, Hs, Ws = shape
+    nc = 5
     H, W = 4 * Hs, 4 * Ws
     lg = rnd(dtype, T * B, nc, Hs, Ws, seed=26).requires_grad_(True)
     fl = [rnd(torch.float32, B, 2, H, W, seed=30 + i) for i in range(T - 1)] if flow else []
