@@ -1,4 +1,4 @@
-"""The element-wise launches the BENCHMARKED plan actually makes (BASELINE.json configs[2]: T=3, B=8, 480x640, bf16, HRNet-w32): every
+"""The element-wise launches the BENCHMARKED plan actually makes (BASELINE.json configs[2]: T=3, B=8, 480x640, bf16, HRNet-w32 and -w48): every
 distinct mfc_combine_fwd / mfc_bnbwd_reduce / mfc_bnbwd_apply / mfc_mask_add record of that plan -- with the plan's own descriptor
 (views, channel slices, mask modes, 1-bit masks, accumulate flags, fused finalize, separable-adjoint scratch, N = 24 images at
 120x160 ... 15x20 and the 480-channel full-resolution tensors) -- is run once on seeded tensors and compared with PyTorch CPU fp32
@@ -263,11 +263,12 @@ def run_mask_add(d0, L, gen):
 RUN = {"combine": run_combine, "reduce": run_reduce, "apply": run_apply, "mask_add": run_mask_add}
 
 
-def test_every_elementwise_record_of_the_benchmarked_plan():
+@pytest.mark.parametrize("width", [32, 48])
+def test_every_elementwise_record_of_the_benchmarked_plan(width):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from mfcnet_amd import _lib as L
-    recs = plan_records(32)
+    recs = plan_records(width)
     kinds = [k[0] for k in recs]
     assert kinds.count("combine") >= 10 and kinds.count("apply") >= 8 and kinds.count("reduce") >= 4 and kinds.count("mask_add") >= 8
     for i, (key, d) in enumerate(recs.items()):
@@ -277,4 +278,4 @@ def test_every_elementwise_record_of_the_benchmarked_plan():
         except AssertionError as e:
             raise AssertionError(f"{key}: {e}") from e
         torch.cuda.synchronize()
-    print(f"w32: {len(recs)} distinct element-wise records ({', '.join(f'{kinds.count(k)} {k}' for k in RUN)}) of the B=8 480x640 bf16 plan match CPU fp32")
+    print(f"w{width}: {len(recs)} distinct element-wise records ({', '.join(f'{kinds.count(k)} {k}' for k in RUN)}) of the B=8 480x640 bf16 plan match CPU fp32")
