@@ -671,6 +671,7 @@ static bool conv_variant_fa(int dtype, int NT, int MT, int PM, int NW);
 
 static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& PM, size_t& lds, int& grid, int& NWsel, int pass = 0) {
     // pass 0 honours MFC_CONV_WANT_FA (fusable geometries only); if none exists the search is repeated unrestricted (pass 1)
+    if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;          // (before anything reads the descriptor)
     bool want_fa = pass == 0 && (d->flags & MFC_CONV_WANT_FA) && mfc_is16(d->dtype);
     if (want_fa) {
         // only where the fused epilogue's cout blocking (NT in {2, 4}) is also the natural one: for 48 / 96 / 192 / 384 channels (HRNet-W48)
@@ -685,7 +686,6 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
         }
         if (ntn != 2 && ntn != 4) want_fa = false;
     }
-    if (!d || !d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
     if (!mfc_dtype_ok(d->dtype)) return MFC_ERR_INVALID_ARG;
     const int E = mfc_is16(d->dtype) ? 8 : 4;
     if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin > d->Cin_p || d->Cout > d->Cout_p) return MFC_ERR_INVALID_ARG;
@@ -839,13 +839,19 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
     return MFC_OK;
 }
 
+// conv3x3_ring.hip
+bool ring_eligible(const mfc_conv_desc* d);
+int ring_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
+int ring_launch(const mfc_conv_desc* d, hipStream_t st);
 // conv_gemm1x1.hip
 bool gemm1x1_eligible(const mfc_conv_desc* d);
 int gemm1x1_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
 int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st);
 
 extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
-    if (d && out && gemm1x1_eligible(d)) return gemm1x1_layout(d, out);
+    if (!d) return MFC_ERR_INVALID_ARG;
+    if (out && ring_eligible(d)) return ring_layout(d, out);
+    if (out && gemm1x1_eligible(d)) return gemm1x1_layout(d, out);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     mfc_conv_desc t = *d;
     if (!t.in) t.in = (const void*)16;
@@ -862,7 +868,9 @@ extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
 }
 
 extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
-    if (d && gemm1x1_eligible(d)) { mfc_conv_layout l; gemm1x1_layout(d, &l); return l.lds_bytes; }
+    if (!d) return MFC_ERR_INVALID_ARG;
+    if (ring_eligible(d)) { mfc_conv_layout l; const int rc = ring_layout(d, &l); return rc < 0 ? rc : l.lds_bytes; }
+    if (gemm1x1_eligible(d)) { mfc_conv_layout l; gemm1x1_layout(d, &l); return l.lds_bytes; }
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
     return rc < 0 ? rc : (int)lds;
@@ -921,6 +929,8 @@ static int conv_dispatch(const ConvK& k, int MT, int PM, int NW, size_t lds, int
 }
 
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
+    if (!d) return MFC_ERR_INVALID_ARG;
+    if (ring_eligible(d)) return ring_launch(d, (hipStream_t)stream);
     const bool fused = d && (d->acc_src || d->bn_y);
     if (d && gemm1x1_eligible(d)) return fused ? MFC_ERR_UNSUPPORTED : gemm1x1_launch(d, (hipStream_t)stream);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
