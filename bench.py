@@ -9,10 +9,16 @@ on synthetic 480x640 T=3 clips, BASELINE.json's metric.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W     # the same under an external launcher
 
-Prints ONE JSON line (rank 0).  `roofline` describes the kernel with the largest total time in a one-stream profiled
-step that runs AFTER the timed region (HIP events around every launch, on the launch stream; rows named as rocprofv3
-names them); `roofline_conv` is the same for the dominant implicit-GEMM convolution; `cpu_baseline` times the CPU
-oracle (the restatement of the reference step, oracle/mfcnet_oracle.py) on this host's cores.
+Prints ONE JSON line (rank 0).  `value` / `ms_per_step` come from the wall clock around EXACTLY the K timed steps (barrier +
+synchronize on both sides, MAX over ranks); every timed step is also bracketed by a HIP event pair on the step's stream and
+`step_ms` gives the median / min / max of those K durations (`value_median` = frames/s at the median step).
+`roofline` describes the DOMINANT KERNEL TEMPLATE (all instantiations of one `__global__` template summed: the convolution
+kernel has a dozen) of a one-stream profiled step that runs AFTER the timed region (HIP events around every launch, on the launch
+stream; rows named as rocprofv3 names them), and carries the whole-step figures: `step_frac` = sum over all launches of the time
+their algorithmic bytes / FLOPs take at the HBM / MFMA peak, divided by the measured step; `step.mfma_frac`, `step.hbm_frac`
+(algorithmic and counter bytes), and the counter bytes against the fused minimum of SURVEY.md 8(d).  `roofline_top` is the
+single instantiation with the largest total time, `roofline_conv` the dominant convolution instantiation; `cpu_baseline` times
+the CPU oracle (the restatement of the reference step, oracle/mfcnet_oracle.py) on this host's cores (median of >= 5 steps).
 """
 import argparse
 import json
@@ -82,6 +88,14 @@ def launch_ranks(args):
     print(lines[0], flush=True)
 
 
+def rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        return None
+
+
 def synth(B, T, H, W, nc, seed, device, depth=False, optflow=False):
     """N(0,1) frames, U[0,1) depth maps, 3*N(0,1) pixel-unit flows (constants), uniform class masks."""
     import torch
@@ -104,11 +118,20 @@ def pmc_traffic(kernel, args):
         return None, None
     path = found[-1]
     with open(path) as f:
-        ks = json.load(f)["kernels"]
+        doc = json.load(f)
+    src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial`)"
+    if kernel is None:                                        # whole step: counter bytes of every kernel of one training step
+        return (doc.get("step") or {}).get("hbm_bytes_per_step"), src
+    ks = doc["kernels"]
+    if isinstance(kernel, (list, tuple)):                     # a template family: launch-weighted mean over its instantiations
+        hit = [(ks[k]["hbm_bytes_per_launch"], n) for k, n in kernel if k in ks]
+        if len(hit) != len(kernel) or not hit:
+            return None, None
+        return round(sum(b * n for b, n in hit) / sum(n for _, n in hit)), src
     v = ks.get(kernel)
     if v is None:
         return None, None
-    return v["hbm_bytes_per_launch"], f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial`)"
+    return v["hbm_bytes_per_launch"], src
 
 
 # ----------------------------------------------------------------------------------------------- CPU baseline (rank 0, N = 1)
@@ -141,22 +164,32 @@ def cpu_baseline(width, T, H, W):
     g = torch.Generator().manual_seed(42)
 
     def timed(fn, n):
-        fn()                                      # warm-up (allocator, thread pool)
-        t0 = time.time()
+        """median of n timed calls after one warm-up call (allocator, thread pool)"""
+        fn()
+        ts = []
         for _ in range(n):
+            t0 = time.time()
             fn()
-        return (time.time() - t0) / n
+            ts.append(time.time() - t0)
+        ts.sort()
+        return ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
 
-    sd = O.hashed_state(O.mfcnet_table("HRNetMulti-Large", width, 5, T, False, False))
-    net = O.Net(sd, "HRNetMulti-Large", width, 5, T).train()
-    opt = O.make_adam(net, 1e-4)
-    frames = [torch.randn(1, 3, H, W, generator=g) for _ in range(T)]
-    mask = torch.randint(0, 5, (1, H, W), generator=g)
-    t_step = timed(lambda: O.train_step(net, opt, frames, mask), 3)
-    net.eval()
-    with torch.no_grad():
-        t_fwd = timed(lambda: net(frames), 3)
-    del net, opt
+    def mfc_step_time(Bc, n):
+        sd = O.hashed_state(O.mfcnet_table("HRNetMulti-Large", width, 5, T, False, False))
+        net = O.Net(sd, "HRNetMulti-Large", width, 5, T).train()
+        opt = O.make_adam(net, 1e-4)
+        frames = [torch.randn(Bc, 3, H, W, generator=g) for _ in range(T)]
+        mask = torch.randint(0, 5, (Bc, H, W), generator=g)
+        t_step = timed(lambda: O.train_step(net, opt, frames, mask), n)
+        t_fwd = None
+        if Bc == 1:
+            net.eval()
+            with torch.no_grad():
+                t_fwd = timed(lambda: net(frames), n)
+        return t_step, t_fwd
+
+    t_step, t_fwd = mfc_step_time(1, 5)
+    t_step2, _ = mfc_step_time(2, 3)
     # BASELINE configs[0]: single-frame model, batch 2, full step (`F.log_softmax(model(x))`, scripts/train_toolpose_segmentation.py:162-163);
     # its "UNet" model type does not exist in the reference (BASELINE.md section 3) -- the single-frame HRNet-W48 stands in
     sds = O.hashed_state(O.hrnet_table(48, 5, ""))
@@ -170,13 +203,16 @@ def cpu_baseline(width, T, H, W):
         loss, _ = O.total_loss(sn(xs), ms, 5)
         loss.backward()
         so.step()
-    t_single = timed(single_step, 2)
+    t_single = timed(single_step, 3)
     return {"value": round(T / t_step, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "host": {"cpu_model": model, "logical_cpus": logical, "usable_cpus": usable, "torch_threads": threads},
-            "sample": f"3 full training steps of the CPU oracle (fwd + loss + bwd + Adam), HRNet-w{width} MFCNet, B=1, T={T}, {H}x{W}, fp32",
-            "fwd_only": {"value": round(T / t_fwd, 4), "unit": "frames/s", "sample": f"3 eval-mode forwards of the same clip (B=1, T={T})"},
+            "host": {"cpu_model": model, "logical_cpus": logical, "usable_cpus": usable, "torch_threads": threads,
+                     "threads_note": "32 of the host's cores: the B=1 convolutions of torch's CPU backend are SLOWER with more (measured 1.1 frames/s at 32 threads, 0.43 at 64)"},
+            "sample": f"median of 5 full training steps (after 1 warm-up) of the CPU oracle (fwd + loss + bwd + Adam), HRNet-w{width} MFCNet, B=1, T={T}, {H}x{W}, fp32",
+            "batch2": {"value": round(2 * T / t_step2, 4), "unit": "frames/s", "sample": f"median of 3 training steps of the same model at B=2 (the GPU side runs B=8 per GPU; "
+                       "the oracle keeps every activation of the autograd graph: ~8 GB per clip at fp32)"},
+            "fwd_only": {"value": round(T / t_fwd, 4), "unit": "frames/s", "sample": f"median of 5 eval-mode forwards of the same clip (B=1, T={T})"},
             "single_frame_b2_step": {"value": round(2 / t_single, 4), "unit": "frames/s",
-                                     "sample": f"2 full training steps of the single-frame HRNet-w48 (model_type 'HRNet'), B=2, {H}x{W}, fp32 "
+                                     "sample": f"median of 3 full training steps of the single-frame HRNet-w48 (model_type 'HRNet'), B=2, {H}x{W}, fp32 "
                                                "(stand-in for BASELINE.json configs[0])"}}
 
 
@@ -219,9 +255,14 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
+    devs = [(socket.gethostname(), local)]
     if world > 1 or args.force_dist:
         import torch.distributed as dist
-        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29577")):      # (--force-dist without a launcher)
+        if "MASTER_PORT" not in os.environ:                 # (--force-dist without a launcher: a free port, not a fixed one)
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
         if args.force_dist:
             os.environ["MFC_DIST_FORCE"] = "1"
@@ -310,12 +351,19 @@ def main():
         L.lib.mfc_set_flag(9, 0)
     for _ in range(args.warmup):
         step()
+    # every timed step is also bracketed by a HIP event pair on the stream the step's programs run on (torch's current stream: the
+    # side lanes / detached stream fork from it and are joined into it before the step ends)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        evs[i][0].record()
         loss = step()
+        evs[i][1].record()
     sync()
     dt = time.perf_counter() - t0
+    ev_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    med_ms = ev_ms[len(ev_ms) // 2] if len(ev_ms) % 2 else 0.5 * (ev_ms[len(ev_ms) // 2 - 1] + ev_ms[len(ev_ms) // 2])
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -345,37 +393,73 @@ def main():
                  "BASELINE.json configs[2]" if (T, H, W, B) == (3, 480, 640, 8) else
                  "per-GPU share of BASELINE.json configs[4]" if (T, H, W, B, args.width) == (5, 720, 960, 8, 48) else "custom size")
     if rank == 0:
-        roof = roof_conv = None
+        roof = roof_conv = roof_top = None
+        step_ms = dt / args.steps * 1e3
         timed_rows = [r for r in rows if r["bytes"] > 0 or r["flops"] > 0]
         if timed_rows:
-            top = timed_rows[0]                                                   # rows come sorted by total time
-            roof = roofline_of(top, prof_steps, args.dtype, pmc_traffic(top["name"], args))
+            peak = PEAK_TFLOPS[args.dtype]
             tot_ms = sum(r["ms"] for r in rows)
-            fam = lambda pre: [r for r in rows if r["name"].startswith(pre)]
-            def fam_sum(pre):
-                rs = fam(pre)
-                ms, fl, by = sum(r["ms"] for r in rs), sum(r["flops"] for r in rs), sum(r["bytes"] for r in rs)
-                return {"ms_per_step": round(ms / prof_steps, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms and fl else None,
-                        "gbps": round(by / (ms * 1e-3) / 1e9, 1) if ms and by else None}
-            roof.update({"share_of_profiled_step": round(top["ms"] / tot_ms, 4), "profiled_step_ms": round(tot_ms / prof_steps, 3),
-                         "profiled_steps": prof_steps, "profiled_step_streams": "serial, after the timed region",
-                         "families": {k: fam_sum(k) for k in ("conv_igemm_kernel", "conv_gemm1x1_kernel", "conv_wgrad", "wgrad_gemm1x1_kernel",
-                                                                "bnbwd_", "combine_", "mask_add", "bn_finalize")},
-                         "top5": [{"kernel": r["name"], "ms_per_step": round(r["ms"] / prof_steps, 3), "launches": r["launches"] // prof_steps}
-                                  for r in rows[:5]]})
-            convs = [r for r in timed_rows if r["name"].startswith("conv_igemm_kernel")]
+            # ---- per-TEMPLATE families (every instantiation of one __global__ template is one kernel)
+            fams = {}
+            for r in rows:
+                f = fams.setdefault(r["name"].split("<")[0], {"name": r["name"].split("<")[0], "ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "members": []})
+                f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["bytes"] += r["bytes"]; f["launches"] += r["launches"]
+                f["members"].append((r["name"], r["launches"]))
+            dom = max((f for f in fams.values() if f["bytes"] > 0 or f["flops"] > 0), key=lambda f: f["ms"])
+            roof = roofline_of(dom, prof_steps, args.dtype, pmc_traffic(dom["members"], args))
+            roof["kernel"] = dom["name"] + "<...> (" + str(len(dom["members"])) + " instantiations of one template)"
+            # ---- the whole step against the roofs
+            roof_ms = sum(max(r["bytes"] / (PEAK_HBM_GBPS * 1e9), r["flops"] / (peak * 1e12)) for r in rows) * 1e3 / prof_steps
+            flops_step = sum(r["flops"] for r in rows) / prof_steps
+            bytes_step = sum(r["bytes"] for r in rows) / prof_steps
+            ctr_bytes, ctr_src = pmc_traffic(None, args)
+            plan = next(iter(getattr(model, "_plans", {}).values()), None)
+            fused_min = None
+            if plan is not None and not args.fwd_only:
+                # every convolution input read once and every output written once in the forward pass, x3 for training
+                # (one read of each saved activation and one write + read of each activation gradient), + Adam's 28 B per parameter
+                fused_min = 3 * sum(o[1].t.nbytes + o[2].nbytes for o in plan.ops if o[0] == "conv") + 28 * model._np
+            roof.update({
+                "step_frac": round(roof_ms / step_ms, 4),
+                "step": {"ms": round(step_ms, 3), "roof_ms": round(roof_ms, 3),
+                         "roof_ms_is": "sum over every launch of a step of max(algorithmic bytes / 8 TB/s, FLOPs / dense MFMA peak)",
+                         "mfma_tflops": round(flops_step / (step_ms * 1e-3) / 1e12, 1), "mfma_frac": round(flops_step / (step_ms * 1e-3) / 1e12 / peak, 4),
+                         "algorithmic_gb": round(bytes_step / 1e9, 2), "hbm_frac_algorithmic": round(bytes_step / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         "counter_gb": round(ctr_bytes / 1e9, 2) if ctr_bytes else None,
+                         "hbm_frac_counters": round(ctr_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if ctr_bytes else None,
+                         "counter_source": ctr_src,
+                         "fused_minimum_gb": round(fused_min / 1e9, 2) if fused_min else None,
+                         "counters_over_fused_minimum": round(ctr_bytes / fused_min, 2) if (ctr_bytes and fused_min) else None,
+                         "serial_step_ms": round(tot_ms / prof_steps, 3), "records_per_step": (len(plan.fwd_prog) + len(plan.bwd_prog)) if (plan is not None and hasattr(plan, "bwd_prog")) else None},
+                "share_of_profiled_step": round(dom["ms"] / tot_ms, 4), "profiled_step_ms": round(tot_ms / prof_steps, 3),
+                "profiled_steps": prof_steps, "profiled_step_streams": "serial, after the timed region",
+                "families": {f["name"]: {"ms_per_step": round(f["ms"] / prof_steps, 3), "launches": f["launches"] // prof_steps,
+                                         "tflops": round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 2) if f["ms"] and f["flops"] else None,
+                                         "gbps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1) if f["ms"] and f["bytes"] else None,
+                                         "mfma_frac": round(f["flops"] / (f["ms"] * 1e-3) / 1e12 / peak, 4) if f["ms"] and f["flops"] else None,
+                                         "hbm_frac": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if f["ms"] and f["bytes"] else None}
+                             for f in sorted(fams.values(), key=lambda f: -f["ms"])[:14]},
+                "top5": [{"kernel": r["name"], "ms_per_step": round(r["ms"] / prof_steps, 3), "launches": r["launches"] // prof_steps}
+                         for r in rows[:5]]})
+            top = timed_rows[0]                                                   # rows come sorted by total time
+            roof_top = roofline_of(top, prof_steps, args.dtype, pmc_traffic(top["name"], args))
+            convs = [r for r in timed_rows if r["name"].startswith(("conv_igemm_kernel", "conv3x3_ring_kernel"))]
             if convs:
                 roof_conv = roofline_of(convs[0], prof_steps, args.dtype, pmc_traffic(convs[0]["name"], args))
         out = {"metric": f"frames/sec ({H}x{W}, T={T}, HRNet {'single-frame' if args.single else 'MFCNet'}) {'fwd' if args.fwd_only else 'fwd+bwd'}", "value": round(world * B * T * args.steps / dt, 2),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "step_ms": {"median": round(med_ms, 3), "min": round(ev_ms[0], 3), "max": round(ev_ms[-1], 3), "n": len(ev_ms),
+                           "how": "HIP event pair around every timed step, on the step's stream (this rank)"},
+               "value_median": round(world * B * T / (med_ms * 1e-3), 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"{'single-frame HRNet' if args.single else 'MFCNet'}{'-Basic' if args.basic else ''} T={T} {'RGB' + extra if extra else 'RGB-only'} (HRNet-w{args.width} base), {H}x{W}, batch={B}/GPU, {'eval forward only' if args.fwd_only else 'fwd+bwd+Adam'} "
                                       f"({cfg_label})", "width": args.width, "global_batch": world * B,
                           "frames_per_clip": T, "parallelism": f"dp{world}", "ranks": world,
                           "backend": (args.backend if world > 1 else None), "launcher": os.environ.get("MFC_BENCH_LAUNCHER", "external" if external else "bench.py"),
+                          "devices": [f"{h}:cuda{d}" for h, d in devs], "rccl_version": rccl_version(torch) if dist is not None and args.backend == "nccl" else None,
                           "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
-               "roofline": roof, "roofline_conv": roof_conv}
+               "roofline": roof, "roofline_top": roof_top, "roofline_conv": roof_conv}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width, T, H, W)
         print(json.dumps(out), flush=True)

@@ -191,10 +191,23 @@ extern "C" int mfc_confusion_counts(const float* outputs, const int64_t* target,
 
 // ------------------------------------------------------------------ Adam
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float step_size,
-                                                   float beta1, float beta2, float eps, float inv_bc2_sqrt, float gscale, const int* skip) {
+                                                   float beta1, float beta2, float eps, float inv_bc2_sqrt, float gscale, const int* skip,
+                                                   float lr, int step) {
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    if (skip && *skip) return;               // (guarded step: the gradients of this step are not finite -- leave p, m, v alone)
+    if (skip) {
+        if (skip[0]) return;                 // (guarded step: the gradients of this step are not finite -- leave p, m, v alone)
+        // bias correction from the steps actually APPLIED (torch.cuda.amp.GradScaler + Adam: a skipped step does not advance the
+        // optimizer's step count); skip[1] = number of skipped steps so far.  Without skipped steps the host's double-precision
+        // corrections are used unchanged.
+        const int nskip = skip[1];
+        if (nskip > 0) {
+            const float eff = (float)max(step - nskip, 1);
+            const float bc1 = 1.f - exp2f(eff * log2f(beta1)), bc2 = 1.f - exp2f(eff * log2f(beta2));
+            step_size = lr / bc1;
+            inv_bc2_sqrt = rsqrtf(bc2);
+        }
+    }
     if (i + 4 <= n) {
         float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
         float* pp = (float*)&P; float* gg = (float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
@@ -267,7 +280,7 @@ static int adam_step_impl(float* p, const float* g, float* m, float* v, int64_t 
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     const long blocks = ((n + 3) / 4 + 255) / 256;
     if (g_mfc_prof_on == 1) mfc_prof_before((hipStream_t)stream, "adam_kernel", 0.0, 28.0 * (double)n);
-    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale, (const int*)skip_flag);
+    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale, (const int*)skip_flag, lr, (int)step);
     MFC_PROF_END((hipStream_t)stream);
     MFC_CHECK_LAUNCH();
     return MFC_OK;

@@ -11,4 +11,5 @@ from .optim import FlatAdam  # noqa: F401
 from .loss import mfc_loss  # noqa: F401
 from .metrics import confusion_counts, get_metrics  # noqa: F401
 from .checkpoint import load_base_model_weights, load_model_weights, save_model  # noqa: F401
-from .engine import eval_step, train_step  # noqa: F401
+from .engine import LossScaler, eval_step, train_step  # noqa: F401
+from .dist import DataParallel  # noqa: F401

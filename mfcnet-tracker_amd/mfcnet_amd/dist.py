@@ -62,6 +62,32 @@ def broadcast_params(model, src=0, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
+class DataParallel(torch.nn.Module):
+    """Drop-in for the reference's `model = nn.DataParallel(model)` (scripts/train_multiframe_detection.py:107-110,
+    infer_multiframe_endovis15.py:330-333) in a one-process-per-GPU launch: exposes `.module` (the scripts reach `model.module.base_model`,
+    `model.module.multiframe_net`, and `save_model` strips the `module.` prefix, utils/model_utils.py:6-12), forwards calls unchanged, and --
+    when a process group with more than one rank exists -- starts every rank from rank 0's weights and overlaps the RCCL all-reduce of the
+    gradient buckets with the backward pass (GradBucketReducer).  `finish()` (or `mfcnet_amd.train_step`) completes the exchange before
+    the optimizer step.  `device_ids` / `output_device` / `dim` are accepted and ignored: the process owns one device."""
+
+    def __init__(self, module, device_ids=None, output_device=None, dim=0, group=None, average=False, broadcast=True):
+        super().__init__()
+        self.module = module
+        self.group = group
+        self.reducer = None
+        if _active(group):
+            if broadcast:
+                broadcast_params(module, 0, group)
+            self.reducer = GradBucketReducer(module, average=average, group=group)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def finish(self):
+        """wait for the bucket all-reduces the last backward started (no-op with one rank)"""
+        return self.reducer.finish() if self.reducer is not None else []
+
+
 class GradBucketReducer:
     """Overlap the gradient all-reduce with the backward pass: the backward program is cut into segments that
     finalise the flat gradient arena bucket by bucket (plan.py::_build_grad_buckets); after each segment has been enqueued,
@@ -72,8 +98,12 @@ class GradBucketReducer:
         loss.backward(); red.finish(); opt.step()
     """
 
-    def __init__(self, model, average=True, group=None):
+    def __init__(self, model, average=True, group=None, wire_dtype=None):
+        """wire_dtype = torch.bfloat16 / torch.float16: the buckets travel in 16 bits (half the xGMI bytes: 82 MB instead of 164 MB per step
+        for W32) and are accumulated back into the fp32 arena on arrival -- every rank rounds its own contribution once, the sum itself is
+        RCCL's 16-bit ring sum, so this trades gradient precision for link time; off (fp32 buckets) by default."""
         self.model, self.average, self.group = model, average, group
+        self.wire_dtype = wire_dtype
         self.works, self.ranges = [], []
         self._comm = None
         model.grad_bucket_hook = self._on_bucket
@@ -97,15 +127,27 @@ class GradBucketReducer:
             self._comm.wait_stream(torch.cuda.current_stream())
             L.check(L.lib.mfc_wait_detached(C.c_void_p(self._comm.cuda_stream)), "mfc_wait_detached")
             with torch.cuda.stream(self._comm):
+                if self.wire_dtype is not None:
+                    wire = sl.to(self.wire_dtype)
+                    work = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
+                    self.works.append((work, sl, self.average and not avg, wire))
+                    return
                 work = dist.all_reduce(sl, op=op, group=self.group, async_op=True)
         else:
+            if self.wire_dtype is not None:
+                wire = sl.to(self.wire_dtype)
+                work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.works.append((work, sl, self.average, wire))
+                return
             work = dist.all_reduce(sl, op=op, group=self.group, async_op=True)
-        self.works.append((work, sl, self.average and not avg))
+        self.works.append((work, sl, self.average and not avg, None))
 
     def finish(self):
         ws = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        for w, sl, div in self.works:
+        for w, sl, div, wire in self.works:
             w.wait()
+            if wire is not None:
+                sl.copy_(wire)                      # (fp32 arena <- the 16-bit sum)
             if div:
                 sl.div_(ws)
         self.works = []

@@ -38,11 +38,38 @@ def reduce_gradients(model, world_size, group=None):
         allreduce_grads(model, world_size, group=group, average=False)
 
 
-def loss_scale_for(model, output) -> float:
-    """Static loss scale of a step.  1 for fp32 / bf16 storage.  fp16 storage (BASELINE configs[4]) keeps gradients in IEEE half, whose
+class LossScaler:
+    """Loss scale of fp16 training that adapts without a host round trip per step (torch.cuda.amp.GradScaler's policy: halve after a step
+    whose gradients overflowed, double after `growth_interval` clean steps).  The overflow check and the skip of the update happen on
+    the device (mfc_grad_check / mfc_adam_step_guarded); this object only reads the 4-byte skipped-step counter every `check_every`
+    steps -- the scale therefore reacts with a delay of at most that many (skipped, hence harmless) steps."""
+
+    def __init__(self, init_scale, growth_interval=2000, check_every=25, min_scale=1.0, max_scale=2.0 ** 24):
+        self.scale, self.growth_interval, self.check_every = float(init_scale), int(growth_interval), int(check_every)
+        self.min_scale, self.max_scale = float(min_scale), float(max_scale)
+        self._steps, self._clean, self._seen = 0, 0, 0
+
+    def update(self, optimizer):
+        self._steps += 1
+        self._clean += 1
+        if self._steps % self.check_every:
+            return
+        skipped = optimizer.skipped_steps() if hasattr(optimizer, "skipped_steps") else 0
+        if skipped > self._seen:                       # overflow(s) since the last look: back off
+            self._seen = skipped
+            self.scale = max(self.scale * 0.5, self.min_scale)
+            self._clean = 0
+        elif self._clean >= self.growth_interval:
+            self.scale = min(self.scale * 2.0, self.max_scale)
+            self._clean = 0
+
+
+def loss_scale_for(model, output, world_size=1) -> float:
+    """Loss scale of a step.  1 for fp32 / bf16 storage.  fp16 storage (BASELINE configs[4]) keeps gradients in IEEE half, whose
     smallest normal is 6.1e-5 while a logit gradient of the mean-reduced loss is about 1 / (B*H*W) (4e-7 at B=8, 480x640): the loss is
     multiplied by a power of two near B*H*W / 16 (largest logit gradient, class weight 1000, stays below ~64) and FlatAdam divides it
-    out in fp32.  `model.loss_scale` (a number) overrides the rule."""
+    out in fp32.  `model.loss_scale` (a number) overrides the rule; `model.loss_scaler` (a LossScaler, created by train_step on first use
+    unless `model.loss_scale` pins the scale) adapts it.  B is the GLOBAL batch (world_size x the local one): the loss is normalised over it."""
     from . import _lib as L
     if getattr(model, "compute_dtype", None) != L.F16:
         return 1.0
@@ -50,8 +77,11 @@ def loss_scale_for(model, output) -> float:
     if s:
         return float(s)
     import math
+    sc = getattr(model, "loss_scaler", None)
+    if sc is not None:
+        return sc.scale
     B, _, H, W = output.shape
-    return float(2 ** max(0, round(math.log2(max(B * H * W / 16.0, 1.0)))))
+    return float(2 ** max(0, round(math.log2(max(B * max(int(world_size), 1) * H * W / 16.0, 1.0)))))
 
 
 def train_step(model, optimizer, input, mask, optflow=None, depth=None, loss_wts=(0.7, 0.3),
@@ -62,13 +92,17 @@ def train_step(model, optimizer, input, mask, optflow=None, depth=None, loss_wts
     optimizer.zero_grad()
     output = _forward(model, input, optflow, depth)
     loss, acc = mfc_loss(output, mask, class_weights, loss_wts[0], loss_wts[1], global_batch=world_size > 1, group=group)
-    scale = loss_scale_for(model, output)
+    scale = loss_scale_for(model, output, world_size)
+    if scale != 1.0 and getattr(model, "loss_scaler", None) is None and not getattr(model, "loss_scale", None):
+        model.loss_scaler = LossScaler(scale)          # fp16: starts at the static rule's value, then adapts
     (loss if scale == 1.0 else loss * scale).backward()
     reduce_gradients(model, world_size, group)
     if scale == 1.0:
         optimizer.step()
     else:
         optimizer.step(grad_scale=1.0 / scale)
+        if getattr(model, "loss_scaler", None) is not None:
+            model.loss_scaler.update(optimizer)
     return output.detach(), acc
 
 

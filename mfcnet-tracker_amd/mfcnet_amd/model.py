@@ -161,6 +161,14 @@ class HRNetMultiHIP(nn.Module):
                 if e.kind == "bn_rv":
                     bufs[e.name].fill_(1.0)
 
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel on a multi-GPU node (scripts/train_multiframe_detection.py:107-110 wraps unconditionally) replicates the module
+        onto every visible device from one process; this model owns per-device arenas, plans and streams, so that cannot work -- say so
+        instead of failing somewhere inside replicate().  With ONE visible device nn.DataParallel never replicates and works unchanged."""
+        raise L.MfcError("the MI355X MFCNet cannot be replicated by nn.DataParallel: run one process per GPU (torchrun / bench.py --gpus N) "
+                         "and wrap the model in mfcnet_amd.DataParallel(model), which exposes .module like nn.DataParallel and "
+                         "all-reduces the gradients over RCCL (INTEGRATION.md)")
+
     def _apply(self, fn, recurse=True):
         super()._apply(fn, recurse)
         cur = {n: p.data for n, p in self.named_parameters()}

@@ -10,8 +10,10 @@ parameters (name, params, lr, betas, eps), so the reference's `StepLR(optimizer,
 (train_multiframe_detection.py:152-157) and every other `lr_scheduler` drive it unchanged -- `step()` reads each
 group's current `lr`.  A segment whose parameters all have `requires_grad=False` gets no group and is never
 updated: with the per-frame network frozen (the reference's default mode, :159-165: `optim.Adam(
-model.multiframe_net.parameters())`) only the temporal head moves.  Frozen parameters inside a trainable segment
-see a zero gradient (their moments stay zero, so they do not move either).
+model.multiframe_net.parameters())`) only the temporal head moves.  Frozen parameters inside a trainable segment are
+SKIPPED, like torch.optim.Adam skips parameters whose `.grad` is None: a segment is updated as its maximal runs of
+consecutive trainable parameters (one launch per run), so a parameter frozen after some steps keeps its value and its
+moments instead of drifting on stale momentum.
 
 Checkpoints: `state_dict()` stores the two moment arenas as flat tensors (layout "flat-arena-v1"), not torch
 Adam's per-parameter dict, so the 'optimizer' entry of a file written with FlatAdam loads into FlatAdam only (and
@@ -68,18 +70,36 @@ class FlatAdam(torch.optim.Optimizer):
                 self._flag = torch.zeros(2, dtype=torch.int32, device=mdl._P.device)
             L.check(L.lib.mfc_grad_check(mdl._G.data_ptr(), mdl._G.numel(), self._flag.data_ptr(), st), "mfc_grad_check")
         for g in self.param_groups:
-            a, b = g["segment"]
-            for p in g["params"]:
-                if not p.requires_grad:                 # frozen inside a trainable segment: zero gradient -> zero moments -> no update
-                    off = (p.data_ptr() - mdl._P.data_ptr()) // 4
-                    mdl._G[off:off + p.numel()].zero_()
-            args = (mdl._P.data_ptr() + 4 * a, mdl._G.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, b - a,
-                    float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self.step_count, grad_scale)
-            if guard:
-                L.check(L.lib.mfc_adam_step_guarded(*args, self._flag.data_ptr(), st), "mfc_adam_step_guarded")
-            else:
-                L.check(L.lib.mfc_adam_step(*args, st), "mfc_adam_step")
+            for a, b in self._runs(g):
+                args = (mdl._P.data_ptr() + 4 * a, mdl._G.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a, self.v.data_ptr() + 4 * a, b - a,
+                        float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self.step_count, grad_scale)
+                if guard:
+                    # (bias correction from the number of steps actually APPLIED: step_count minus the skipped ones, read on the device)
+                    L.check(L.lib.mfc_adam_step_guarded(*args, self._flag.data_ptr(), st), "mfc_adam_step_guarded")
+                else:
+                    L.check(L.lib.mfc_adam_step(*args, st), "mfc_adam_step")
         return loss
+
+    def _runs(self, g):
+        """maximal runs [a, b) of consecutive trainable parameters of a group's segment (the whole segment when nothing in it is frozen)"""
+        key = tuple(p.requires_grad for p in g["params"])
+        cache = g.setdefault("_runs", {})
+        if key not in cache:
+            base = self.model._P.data_ptr()
+            spans = sorted(((p.data_ptr() - base) // 4, (p.numel() + 3) // 4 * 4, p.requires_grad) for p in g["params"])      # (16-byte padded, as the arena lays them out)
+            runs = []
+            for off, n, tr in spans:
+                if not tr:
+                    continue
+                if runs and runs[-1][1] == off:
+                    runs[-1][1] = off + n
+                else:
+                    runs.append([off, off + n])
+            if all(t for _, _, t in spans):
+                runs = [list(g["segment"])]                  # (alignment padding between parameters included: one launch)
+            cache.clear()
+            cache[key] = [tuple(r) for r in runs]
+        return cache[key]
 
     def skipped_steps(self) -> int:
         """guarded steps whose gradients were not finite (one host read)"""

@@ -75,6 +75,19 @@ def test_descriptors_are_validated_before_any_launch(L):
     d.Cin_p = 16
     lay = L.conv_layout(d)                                          # geometry query needs no GPU
     assert lay.TA == 3 and lay.NT16 == 16 and lay.bytes > 0 and lay.lds_bytes <= 80 * 1024
+    # NULL descriptors are an invalid argument for every convolution entry point, not a crash (round-2 advisor finding)
+    lay2 = L.ConvLayout()
+    assert L.lib.mfc_conv2d_layout(None, C.byref(lay2)) == -1
+    assert L.lib.mfc_conv2d_lds_bytes(None) == -1
+    assert L.lib.mfc_conv2d_fwd(None, None) == -1
+    # the LDS-DMA ring kernel takes the 32 / 64-channel 3x3 BasicBlock convolutions: its weight image is [tap][granule][cout]
+    r = L.ConvDesc(16, 16, 16, 0, 0, 0, L.BF16, 24, 120, 160, 32, 32, 120, 160, 32, 32, 120, 160, 3, 3, -1, -1, 1, 1, 1, 0, 0, 0, 8, 0, 0, 0)
+    lr = L.conv_layout(r)
+    assert (lr.KG, lr.nchunks, lr.Yblocks, lr.NT16, lr.nslots, lr.TAS, lr.fa) == (4, 1, 1, 32, 36, 3, 1) and lr.bytes == 9 * 32 * 32 * 2
+    assert 2 * lr.lds_bytes <= 160 * 1024                           # two workgroups per CU
+    L.lib.mfc_set_flag(30, 0)
+    assert L.conv_layout(r).nslots != 36 or L.conv_layout(r).NT16 != 32 or L.conv_layout(r).fa == 1      # (conv_igemm's own blocking)
+    L.lib.mfc_set_flag(30, 1)
 
 
 def test_model_mirrors_reference_interface():
@@ -106,6 +119,18 @@ def test_model_mirrors_reference_interface():
     x = [torch.zeros(1, 3, 64, 96) for _ in range(3)]
     with pytest.raises(mfc.MfcError):                               # no CPU fallback: the product path fails loudly
         m(x, optflow=[torch.zeros(1, 2, 64, 96)] * 2, depth=[torch.zeros(1, 1, 64, 96)] * 3)
+
+
+def test_data_parallel_replication_is_refused_with_a_clear_error():
+    """scripts/train_multiframe_detection.py:107-110 wraps the model in nn.DataParallel; on a multi-GPU node that replicates the module
+    from one process, which this model cannot do: it must say so (and name the stand-in), not fail inside replicate()."""
+    import mfcnet_amd as mfc
+    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, width=32)
+    with pytest.raises(mfc.MfcError, match="mfcnet_amd.DataParallel"):
+        m._replicate_for_data_parallel()
+    dp = mfc.DataParallel(m)                      # no process group: a transparent wrapper
+    assert dp.module is m and dp.reducer is None and next(iter(dp.state_dict())).startswith("module.")
+    assert dp.module.base_model is m.base_model and dp.module.multiframe_net is m.multiframe_net
 
 
 def test_plan_builds_without_gpu():

@@ -11,6 +11,13 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -32,7 +39,7 @@ def _worker(rank, world, port, q):
 def test_two_rank_gradient_allreduce_and_broadcast():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -111,6 +118,54 @@ def test_two_rank_bucketed_overlap_reducer():
     q = ctx.Queue()
     port = 33500 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def _wire_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mfcnet_amd.dist import DataParallel, GradBucketReducer
+    n = 4096
+    g = torch.Generator().manual_seed(11 + rank)
+    model = SimpleNamespace(_G=torch.randn(n, generator=g), _P=torch.full((n,), float(rank)), _RS=torch.zeros(3), _NBT=torch.zeros(1, dtype=torch.int64))
+    mine = model._G.clone()
+    both = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(both, mine)
+    # 16-bit wire format: every rank rounds its contribution to bf16, the sum comes back into the fp32 arena
+    red = GradBucketReducer(model, average=False, wire_dtype=torch.bfloat16)
+    model.grad_bucket_hook(0, n // 2)
+    model.grad_bucket_hook(n // 2, n)
+    ranges = red.finish()
+    want = sum(b.to(torch.bfloat16).float() for b in both)
+    ok = ranges == [(0, n // 2), (n // 2, n)] and torch.allclose(model._G, want, rtol=2e-2, atol=2e-2) and model._G.dtype == torch.float32
+    # the nn.DataParallel stand-in: .module, rank 0's weights everywhere, a reducer installed
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self._G, self._P, self._RS, self._NBT = torch.zeros(8), torch.full((8,), float(rank + 3)), torch.zeros(2), torch.zeros(1, dtype=torch.int64)
+        def forward(self, x, k=1):
+            return x * k
+    dp = DataParallel(M(), device_ids=[0])
+    ok = ok and dp.module._P.eq(3.0).all().item() and dp.reducer is not None and float(dp(torch.ones(1), k=2)) == 2.0
+    ok = ok and list(dp.state_dict().keys()) == [] and dp.finish() == []
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sixteen_bit_gradient_buckets_and_dataparallel_stand_in():
+    """dist.GradBucketReducer(wire_dtype=bf16) and mfcnet_amd.DataParallel (the replacement of scripts/train_multiframe_detection.py:107-110)
+    over two gloo ranks"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wire_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(2))

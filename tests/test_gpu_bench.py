@@ -8,6 +8,14 @@ import sys
 import pytest
 import torch
 
+def _free_port():
+    """a port nobody listens on right now (two sessions sharing a box must not collide on a fixed one)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 SMALL = ["--steps", "3", "--warmup", "1", "--batch", "2", "--height", "96", "--width-px", "128", "--no-cpu-baseline"]
@@ -62,7 +70,7 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     _need_gpu()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-prof"] + SMALL
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-prof"] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     d = _json_line(r.stdout)
@@ -94,7 +102,7 @@ def test_overlapped_bucket_allreduce_equals_the_plain_order():
     _need_gpu()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29537", os.path.join(ROOT, "tests", "dist_overlap_check.py")]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_overlap_check.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     print(r.stdout[-3000:])
     print(r.stderr[-3000:])

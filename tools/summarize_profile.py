@@ -143,11 +143,17 @@ def main():
         fe, wr = pmc_avg(pf, "FETCH_SIZE"), pmc_avg(pw, "WRITE_SIZE")
         out = {"note": "per-dispatch averages over one serial training step; FETCH_SIZE doubled (gfx950 wide-read correction), units of 1024 B",
                "kernels": {}}
+        nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 2          # training steps of the profiled command (tools/profile_round.sh: --warmup 1 --steps 1)
+        step_bytes = 0.0
         for n in fe:
             f_kb, calls = fe[n]
             w_kb = wr.get(n, (0.0, 0))[0]
             out["kernels"][n] = {"dispatches": calls, "fetch_size_raw_kb": round(f_kb, 1), "write_size_kb": round(w_kb, 1),
                                  "hbm_bytes_per_launch": round((2.0 * f_kb + w_kb) * 1024.0)}
+            if not any(n.startswith(p) for p in SETUP):
+                step_bytes += (2.0 * f_kb + w_kb) * 1024.0 * calls
+        out["step"] = {"steps_in_run": nsteps, "hbm_bytes_per_step": round(step_bytes / nsteps),
+                       "note": "counter bytes of every kernel of the run except model set-up (copies, fills, weight packing), divided by the steps of the run"}
         with open(os.path.join(root, "profiles", f"{tag}_pmc_traffic.json"), "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
         for n in sorted(out["kernels"], key=lambda k: -out["kernels"][k]["hbm_bytes_per_launch"] * out["kernels"][k]["dispatches"])[:8]:
