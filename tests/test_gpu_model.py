@@ -222,8 +222,9 @@ def test_bf16_small_shapes_vs_storage_oracle_and_fp32(mfc):
     l32.backward()
     g32 = m32.multiframe_net.multiframe_net[0].weight.grad.cpu()
     cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
-    print("bf16 vs fp32 head-gradient cosine", cos, "loss", float(loss), float(l32))
-    assert cos > 0.6 and bool(torch.isfinite(m._G).all()) and abs(float(loss.detach()) - float(l32.detach())) < 0.02
+    print("bf16 vs fp32 head-gradient cosine (11x11 weight, information only: the gradients are checked against the CPU oracle in "
+          "test_16bit_gradients_against_the_fp32_oracle)", cos, "loss", float(loss), float(l32))
+    assert bool(torch.isfinite(m._G).all()) and abs(float(loss.detach()) - float(l32.detach())) < 0.02
 
 
 def test_fp16_storage_eval_and_scaled_training_step(mfc):
@@ -254,6 +255,65 @@ def test_fp16_storage_eval_and_scaled_training_step(mfc):
     assert cos > 0.9 and abs(float(acc[28]) - float(l32.detach())) < 5e-3
     moved = (m._P - p0).abs()
     assert float(moved.max()) <= 1.001e-4 and float((moved > 0.9e-4 / 3).float().mean()) > 0.5       # |first Adam step| = lr (head) or lr / T (base group) where g != 0
+
+
+def _oracle_grads(sd, cfg, width, frames, mask):
+    from oracle import mfcnet_oracle as O
+    net = O.Net(sd, cfg["model_type"], width, 5, cfg["T"]).train()
+    out = net(frames)
+    loss, _ = O.total_loss(out, mask, 5)
+    loss.backward()
+    return {n: net.sd[n].grad.detach().clone() for n in net.param_names}, float(loss)
+
+
+def _cos_rel(ref, got, names):
+    a = torch.cat([ref[n].flatten() for n in names]).double()
+    b = torch.cat([got[n].flatten() for n in names]).double()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300)), float((a - b).norm() / (a.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("damp", [0.1, 1.0], ids=["damped-residuals", "hashed-weights"])
+def test_16bit_gradients_against_the_fp32_oracle(mfc, damp):
+    """bf16 / fp16 GRADIENTS of a whole training step (HRNet-w32 MFCNet, T=3, B=2, 128x192) against the CPU oracle's fp32 autograd
+    gradients -- not against this library's own fp32 build.  What limits them is localised in tests/fidelity_probe.py
+    (profiles/r03_fidelity_probe.txt): rounding the GRADIENT tensors to 16 bits is harmless (cosine 0.9998 / 0.9999 with the whole
+    backward rounded to bf16 / fp16 on an fp32 forward), rounding the FORWARD tensors is what moves the gradient, and by how much
+    depends on how chaotic the network is.  With the key-hashed weights as they are (gamma in U(0.5, 1.5) on every residual branch:
+    a 100-layer random ReLU / BatchNorm network whose early-layer gradients decorrelate under ANY forward perturbation, the
+    reference's own fp32 gradients included -- tests/test_oracle_noise_floor.py) the CPU emulation of bf16 storage reaches cosine
+    0.93 (head) / 0.25 (all parameters), fp16 0.99 / 0.81; with the last BatchNorm weight of every residual block scaled by 0.1
+    (residual branches small against the skip path, the regime of a trained network) bf16 reaches 0.988 / 0.906 and fp16
+    0.998 / 0.988.  The bounds below sit under those emulated values; the sentinel's relative L2 error is printed."""
+    cfg = dict(name="grad16", model_type="HRNetMulti-Large", T=3, optflow=False, depth=False, B=2, H=128, W=192, mode="train")
+    width = 32
+    sd = {k: v.clone() for k, v in case_state(cfg, width).items()}
+    for n in sd:
+        if n.endswith((".bn2.weight", ".bn3.weight")) and (".branches." in n or ".layer1." in n):
+            sd[n] = sd[n] * damp
+    frames, _, _, mask = case_inputs(cfg)
+    ref, lref = _oracle_grads(sd, cfg, width, frames, mask)
+    names = list(ref)
+    head = [n for n in names if n.startswith("multiframe_net.")]
+    sentinel = "multiframe_net.multiframe_net.0.weight"
+    bounds = {(0.1, "bf16"): (0.95, 0.80), (0.1, "fp16"): (0.99, 0.95), (1.0, "bf16"): (0.75, 0.10), (1.0, "fp16"): (0.95, 0.50)}      # (measured on MI355X: 0.988 / 0.911, 0.998 / 0.988, 0.836 / 0.190, fp16 undamped see log)
+    for dtype in ("bf16", "fp16"):
+        m = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, width=width, compute_dtype=dtype)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        y = m(dev(frames))
+        loss, _ = mfc.mfc_loss(y, mask.cuda())
+        scale = mfc.engine.loss_scale_for(m, y)
+        (loss * scale).backward()
+        got = {n: (p.grad / scale).detach().cpu() for n, p in m.named_parameters()}
+        assert all(bool(torch.isfinite(g).all()) for g in got.values())
+        ch, rh = _cos_rel(ref, got, head)
+        ca, ra = _cos_rel(ref, got, names)
+        cs, rs = _cos_rel(ref, got, [sentinel])
+        print(f"{dtype} gradients vs CPU fp32 oracle (residual gamma x{damp}): head cosine {ch:.4f} (rel L2 {rh:.3f}), all parameters {ca:.4f} "
+              f"({ra:.3f}), sentinel {sentinel} {cs:.4f} ({rs:.3f}); loss {float(loss):.5f} vs {lref:.5f}")
+        bh, ba = bounds[(damp, dtype)]
+        assert ch >= bh and ca >= ba and abs(float(loss.detach()) - lref) < 0.02, (dtype, damp, ch, ca)
+        del m
 
 
 def test_fp16_config4_shape_eval_vs_storage_oracle(mfc):
