@@ -268,7 +268,7 @@ int mfc_upsample_nearest2x(const void* src, void* dst, int32_t dtype, int32_t N,
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm / ReLU backward (precedent: inplace_abn_cuda.cu:174-292 edz_eydz + backward).
- *   m     = mask (mode 0: 1; mode 1: mask_src > 0; mode 2: y*scale+shift > 0)
+ *   m     = mask (mode 0: 1; mode 1: mask_src > 0; mode 2: y*scale+shift > 0; mode 3: bit image; mode 4: the SiLU derivative at y*scale+shift)
  *   reduce:   bstats[r][g][0][c] += sum g*m ;  bstats[r][g][1][c] += sum g*m*yhat ;
  *             if dy.ptr is set, the masked gradient is also written out: dy (+)= g*m (`accumulate`) -- the residual /
  *             identity branch of the same sum receives exactly g*m, so one pass serves both (and later passes can
@@ -294,7 +294,8 @@ typedef struct {
     float* fin_dbeta;        /* [fin_C] */
     int32_t fin_C, fin_training;
     float fin_count;
-    int32_t pad_;
+    int32_t gn_mode;         /* apply only: 1 = GroupNorm (nn.GroupNorm of resunet.py:64; statistics per image): bcoef = A, B of mfc_gnbwd_finalize and
+                              * dy = scale * g*m - rstd * (A + yhat * B); the fused finalize is not available in this mode */
 } mfc_bnbwd_desc;
 int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream);
 int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream);
@@ -308,6 +309,27 @@ typedef struct {
     float count;
 } mfc_bnbwdfin_desc;
 int mfc_bnbwd_finalize(const mfc_bnbwdfin_desc* d, void* stream);
+
+/* ---- ResUnet_VB backward (models/resunet.py:46-76, 97-180 under loss.backward(); precedent for the normalisation half: inplace_abn_cuda.cu:174-292).
+ *   SiLU:       mask_mode 4 of mfc_bnbwd_reduce / mfc_bnbwd_apply multiplies the incoming gradient by d silu(z) / dz, z = y*scale + shift
+ *   GroupNorm:  mfc_bnbwd_reduce with images_per_group = 1 leaves per-(image, channel) sums S1 = sum g, S2 = sum g*yhat;
+ *               mfc_gnbwd_finalize folds them into A = mean_{group channels, pixels}(gamma g), B = mean(gamma g yhat) (bcoef [N][2][Cp], per channel)
+ *               and dgamma[c] = sum_n S2, dbeta[c] = sum_n S1 (overwritten); mfc_bnbwd_apply with gn_mode = 1 writes dy = scale g - rstd (A + yhat B)
+ *   weight standardisation: mfc_ws_backward turns the gradient w.r.t. the standardised weights into the gradient w.r.t. the raw ones
+ *   nearest x2: mfc_upsample_nearest2x_bwd sums the four copies (ddst [N, H, W, Cp] (+)= from dsrc [N, 2H, 2W, Cp])                          */
+typedef struct {
+    const mfc_stat_t* bstats; /* [MFC_STAT_REPLICAS][N][2][Cp] */
+    float* bcoef;            /* out [N][2][Cp] */
+    const float* gamma;      /* [C] */
+    float* dgamma;           /* [C] (overwritten) */
+    float* dbeta;            /* [C] (overwritten) */
+    int32_t C, Cp, N, groups;
+    float count;             /* H * W */
+    int32_t pad_;
+} mfc_gnbwdfin_desc;
+int mfc_gnbwd_finalize(const mfc_gnbwdfin_desc* d, void* stream);
+int mfc_ws_backward(const float* w, const float* dws, float* dw, int32_t Cout, int32_t per_out, float eps, void* stream);
+int mfc_upsample_nearest2x_bwd(const void* dsrc, void* ddst, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t Cp, int32_t accumulate, void* stream);
 
 /* dst = (accumulate ? dst : 0) + adjoint_bilinear?( g * m )   -- gradient of identity /
  * up-sampled terms of a combine (residual adds hrnet.py:71,112; fuse sums :250-259).      */
@@ -424,7 +446,10 @@ typedef enum {
     MFC_OP_BNFIN_BATCH = 18,     /* raw.a = DEVICE pointer to an mfc_bnfin_desc array, raw.i[0] = n, raw.i[1] = max Cp */
     MFC_OP_WSNORM = 19,          /* raw.a = w, raw.b = w_out, raw.i[0] = Cout, raw.i[1] = per_out, raw.i[2] = eps (float bits) */
     MFC_OP_GNFIN = 20,           /* gnfin */
-    MFC_OP_UPNEAR = 21           /* raw.a = src, raw.b = dst, raw.i = dtype, N, H, W, Cp */
+    MFC_OP_UPNEAR = 21,          /* raw.a = src, raw.b = dst, raw.i = dtype, N, H, W, Cp */
+    MFC_OP_GNBWD_FIN = 22,       /* gnbwdfin */
+    MFC_OP_WSBWD = 23,           /* raw.a = w, raw.b = dws, raw.c = dw, raw.i[0] = Cout, raw.i[1] = per_out, raw.i[2] = eps (float bits) */
+    MFC_OP_UPNEAR_BWD = 24       /* raw.a = dsrc, raw.b = ddst, raw.i = dtype, N, H, W, Cp, accumulate */
 } mfc_op_kind;
 
 #define MFC_LANE_ASYNC 0x100
@@ -443,6 +468,7 @@ typedef struct {
         mfc_combine_desc combine;
         mfc_bnbwd_desc bnbwd;
         mfc_bnbwdfin_desc bnbwdfin;
+        mfc_gnbwdfin_desc gnbwdfin;
         mfc_maskadd_desc maskadd;
         mfc_headgather_desc head;
         struct { mfc_headgather_desc d; uint64_t dlogits; } headbwd;

@@ -280,6 +280,13 @@ __device__ inline void apply_mask(const mfc_bnbwd_desc& d, const uint4& mraw, co
     } else if (d.mask_mode == 3) {          // one bit per element, one byte per 8-channel granule (written by mfc_combine_fwd)
 #pragma unroll
         for (int e = 0; e < E; ++e) gm[e] = ((mraw.x >> e) & 1u) ? gm[e] : 0.f;
+    } else if (d.mask_mode == 4) {          // SiLU (resunet.py:67): d silu(z) / dz = s (1 + z (1 - s)), s = sigmoid(z), z = y*scale + shift
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float z = yv[e] * cf[e] + cf[d.y.Cp + e];
+            const float sg = 1.f / (1.f + __expf(-z));
+            gm[e] *= sg * (1.f + z * (1.f - sg));
+        }
     }
 }
 // the byte of mask bits of granule (pixel, channel c) of a [.., Cp] tensor
@@ -364,7 +371,7 @@ static int bnbwd_check(const mfc_bnbwd_desc* d, int& E) {
     if (!view_ok(d->g, E) || !view_ok(d->y, E) || !d->y.coef || d->C <= 0 || d->C % E) return MFC_ERR_INVALID_ARG;
     if (d->g.H != d->y.H || d->g.W != d->y.W) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode == 1 && (!view_ok(d->mask, E) || d->mask.H != d->y.H || d->mask.W != d->y.W)) return MFC_ERR_INVALID_ARG;
-    if (d->mask_mode < 0 || d->mask_mode > 3) return MFC_ERR_INVALID_ARG;
+    if (d->mask_mode < 0 || d->mask_mode > 4) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode == 3 && (!mfc_is16(d->dtype) || !d->mask.ptr || d->mask.Cp % 8 || d->mask.c_off % 8 || d->mask.H != d->y.H || d->mask.W != d->y.W)) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
     return MFC_OK;
@@ -458,7 +465,10 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const float yh = (yv[e] - cf[2 * d.y.Cp + e]) * cf[3 * d.y.Cp + e];
-            o[e] = cf[e] * (gm[e] - bc[e] - yh * bc[d.y.Cp + e]);
+            // GroupNorm (gn_mode): the two means span the channels of a group, so they are not scaled by the channel's gamma:
+            // dy = gamma rstd g - rstd (A + yhat B), bcoef = A, B of the channel's group (mfc_gnbwd_finalize)
+            o[e] = d.gn_mode ? (cf[e] * gm[e] - cf[3 * d.y.Cp + e] * (bc[e] + yh * bc[d.y.Cp + e]))
+                             : cf[e] * (gm[e] - bc[e] - yh * bc[d.y.Cp + e]);
         }
         *(uint4*)((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(o);
     }
@@ -532,6 +542,7 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
     int E; int rc = bnbwd_check(d, E); if (rc < 0) return rc;
     if (!view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W) return MFC_ERR_INVALID_ARG;
     if (d->fin_dgamma) {       // finalize fused into this launch
+        if (d->gn_mode) return MFC_ERR_UNSUPPORTED;
         const int G = d->N / d->images_per_group;
         if (!d->bstats || !d->fin_dbeta || d->fin_C <= 0 || d->fin_C > d->C || d->C > 128 || G > 8 || d->fin_count <= 0.f) return MFC_ERR_INVALID_ARG;
         const int Cgf = d->C / E;
@@ -1298,6 +1309,124 @@ extern "C" int mfc_upsample_nearest2x(const void* src, void* dst, int32_t dtype,
     const long total = (long)N * 2 * H * 2 * W * Cg;
     hipLaunchKernelGGL(upsample_nearest2x_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const char*)src, (char*)dst, H, W, Cg, total);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+
+// ------------------------------------------------------------------ ResUnet_VB backward pieces (models/resunet.py:46-76 under loss.backward())
+// GroupNorm backward, finalize: from the per-(image, channel) sums S1 = sum g, S2 = sum g*yhat (mfc_bnbwd_reduce with images_per_group = 1,
+// mask_mode 4 folds the SiLU derivative into g) to  A[n, group] = mean over the group's channels and pixels of gamma*g,  B = the same of
+// gamma*g*yhat  (written per channel into bcoef [N][2][Cp] for mfc_bnbwd_apply with gn_mode), and  dgamma[c] = sum_n S2, dbeta[c] = sum_n S1.
+// One workgroup walks the images one after the other (fixed order: deterministic).
+__global__ __launch_bounds__(256) void gnbwd_finalize_kernel(mfc_gnbwdfin_desc d) {
+    extern __shared__ float gsh[];                 // [2][C] gamma-weighted sums of the current image, then [2][groups]
+    float* w1 = gsh; float* w2 = gsh + d.C; float* ga = gsh + 2 * d.C; float* gb = ga + d.groups;
+    const int cpg = d.C / d.groups;
+    const size_t rstride = (size_t)d.N * 2 * d.Cp;
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};          // channels tid, tid + 256, ... (C <= 1024)
+    for (int n = 0; n < d.N; ++n) {
+        for (int k = 0, c = threadIdx.x; c < d.C; c += 256, ++k) {
+            const double s1 = replica_sum(d.bstats + ((size_t)n * 2 + 0) * d.Cp + c, rstride);
+            const double s2 = replica_sum(d.bstats + ((size_t)n * 2 + 1) * d.Cp + c, rstride);
+            db[k] += (float)s1; dg[k] += (float)s2;
+            w1[c] = d.gamma[c] * (float)s1; w2[c] = d.gamma[c] * (float)s2;
+        }
+        __syncthreads();
+        for (int g = threadIdx.x; g < d.groups; g += 256) {
+            double a = 0.0, b = 0.0;
+            for (int i = 0; i < cpg; ++i) { a += (double)w1[g * cpg + i]; b += (double)w2[g * cpg + i]; }
+            ga[g] = (float)(a / ((double)d.count * cpg)); gb[g] = (float)(b / ((double)d.count * cpg));
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < d.Cp; c += 256) {
+            d.bcoef[((size_t)n * 2 + 0) * d.Cp + c] = c < d.C ? ga[c / cpg] : 0.f;
+            d.bcoef[((size_t)n * 2 + 1) * d.Cp + c] = c < d.C ? gb[c / cpg] : 0.f;
+        }
+        __syncthreads();
+    }
+    for (int k = 0, c = threadIdx.x; c < d.C; c += 256, ++k) { d.dgamma[c] = dg[k]; d.dbeta[c] = db[k]; }
+}
+extern "C" int mfc_gnbwd_finalize(const mfc_gnbwdfin_desc* d, void* stream) {
+    if (!d || !d->bstats || !d->bcoef || !d->gamma || !d->dgamma || !d->dbeta || d->C <= 0 || d->C > d->Cp || d->N <= 0 || d->groups <= 0 ||
+        d->C % d->groups || d->count <= 0.f) return MFC_ERR_INVALID_ARG;
+    if (d->C > 1024) return MFC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gnbwd_finalize_kernel, dim3(1), dim3(256), (size_t)(2 * d->C + 2 * d->groups) * 4, (hipStream_t)stream, *d);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// weight standardisation backward (resunet.py:55-60): w' = (w - mean) * r, r = (var + eps)^-1/2 over the cin*kh*kw weights of an output
+// channel  =>  dw = r * (dw' - mean(dw') - w' * mean(dw' * w')).  One workgroup per output channel; statistics in fp64 as in the forward.
+__global__ __launch_bounds__(256) void ws_backward_kernel(const float* w, const float* dws, float* dw, int per_out, float eps) {
+    __shared__ double ra[256], rb[256];
+    const size_t base = (size_t)blockIdx.x * per_out;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < per_out; i += 256) { const double v = (double)w[base + i]; s += v; q += v * v; }
+    ra[threadIdx.x] = s; rb[threadIdx.x] = q;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) { ra[threadIdx.x] += ra[threadIdx.x + h]; rb[threadIdx.x] += rb[threadIdx.x + h]; }
+        __syncthreads();
+    }
+    const double mean = ra[0] / per_out;
+    double var = rb[0] / per_out - mean * mean; if (var < 0.0) var = 0.0;
+    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+    __syncthreads();
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < per_out; i += 256) {
+        const double g = (double)dws[base + i];
+        a += g; b += g * (double)((w[base + i] - m) * r);
+    }
+    ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) { ra[threadIdx.x] += ra[threadIdx.x + h]; rb[threadIdx.x] += rb[threadIdx.x + h]; }
+        __syncthreads();
+    }
+    const float m1 = (float)(ra[0] / per_out), m2 = (float)(rb[0] / per_out);
+    for (int i = threadIdx.x; i < per_out; i += 256) {
+        const float wh = (w[base + i] - m) * r;
+        dw[base + i] = r * (dws[base + i] - m1 - wh * m2);
+    }
+}
+extern "C" int mfc_ws_backward(const float* w, const float* dws, float* dw, int32_t Cout, int32_t per_out, float eps, void* stream) {
+    if (!w || !dws || !dw || Cout <= 0 || per_out <= 0) return MFC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(ws_backward_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, dws, dw, per_out, eps);
+    MFC_CHECK_LAUNCH();
+    return MFC_OK;
+}
+
+// adjoint of the nearest-neighbour x2 up-sampling: dst[n, h, w, :] (+)= sum of the four src pixels it was copied to (fp32 sum, one rounding)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_nearest2x_bwd_kernel(const char* src, char* dst, int H, int W, int Cg, long total, int accumulate) {
+    constexpr int E = Gran<T>::E;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % Cg); long pix = idx / Cg;
+    const int w = (int)(pix % W); pix /= W;
+    const int h = (int)(pix % H); const long n = pix / H;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    if (accumulate) Gran<T>::unpack(*(const uint4*)(dst + idx * 16), acc);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float f[E];
+            Gran<T>::unpack(*(const uint4*)(src + ((((size_t)n * 2 * H + 2 * h + a) * 2 * W + 2 * w + b) * Cg + g) * 16), f);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += f[e];
+        }
+    *(uint4*)(dst + idx * 16) = Gran<T>::pack(acc);
+}
+extern "C" int mfc_upsample_nearest2x_bwd(const void* dsrc, void* ddst, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t Cp, int32_t accumulate, void* stream) {
+    if (!dsrc || !ddst || N <= 0 || H <= 0 || W <= 0 || Cp <= 0 || Cp % 8 || (!mfc_dtype_ok(dtype))) return MFC_ERR_INVALID_ARG;
+    const int Cg = Cp / (mfc_is16(dtype) ? 8 : 4);
+    const long total = (long)N * H * W * Cg;
+    MFC_TYPED(dtype, T_, hipLaunchKernelGGL(upsample_nearest2x_bwd_kernel<T_>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                            (const char*)dsrc, (char*)ddst, H, W, Cg, total, accumulate));
     MFC_CHECK_LAUNCH();
     return MFC_OK;
 }

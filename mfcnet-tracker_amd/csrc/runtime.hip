@@ -405,6 +405,14 @@ static int run_one(const mfc_op& o, void* stream) {
         case MFC_OP_GNFIN: return mfc_gn_finalize(&o.u.gnfin, stream);
         case MFC_OP_UPNEAR:      // a = src, b = dst, i = dtype, N, H, W, Cp
             return mfc_upsample_nearest2x((const void*)o.u.raw.a, (void*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3], o.u.raw.i[4], stream);
+        case MFC_OP_GNBWD_FIN: return mfc_gnbwd_finalize(&o.u.gnbwdfin, stream);
+        case MFC_OP_WSBWD: {     // a = w, b = dws, c = dw, i[0] = Cout, i[1] = per_out, i[2] = eps (float bits)
+            float eps; memcpy(&eps, &o.u.raw.i[2], 4);
+            return mfc_ws_backward((const float*)o.u.raw.a, (const float*)o.u.raw.b, (float*)o.u.raw.c, o.u.raw.i[0], o.u.raw.i[1], eps, stream);
+        }
+        case MFC_OP_UPNEAR_BWD:  // a = dsrc, b = ddst, i = dtype, N, H, W, Cp, accumulate
+            return mfc_upsample_nearest2x_bwd((const void*)o.u.raw.a, (void*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3], o.u.raw.i[4],
+                                              o.u.raw.i[5], stream);
         default: return MFC_ERR_INVALID_ARG;
     }
 }

@@ -33,6 +33,7 @@ OP_HEAD_FWD, OP_HEAD_BWD, OP_BIAS_GRAD, OP_MEMSET, OP_PACK, OP_UNPACK, OP_NCHW2N
 OP_WGRAD_BATCH = 17
 OP_BNFIN_BATCH = 18
 OP_WSNORM, OP_GNFIN, OP_UPNEAR = 19, 20, 21
+OP_GNBWD_FIN, OP_WSBWD, OP_UPNEAR_BWD = 22, 23, 24
 WGRAD_MAXBATCH = 8
 CONV_WANT_FA = 1
 RUN_DEFER_JOIN = 1
@@ -99,7 +100,12 @@ class CombineDesc(C.Structure):
 class BnBwdDesc(C.Structure):
     _fields_ = [("g", View), ("y", View), ("mask", View), ("dy", View), ("bstats", vp), ("bcoef", vp),
                 ("mask_mode", i32), ("dtype", i32), ("N", i32), ("C", i32), ("images_per_group", i32), ("accumulate", i32),
-                ("fin_dgamma", vp), ("fin_dbeta", vp), ("fin_C", i32), ("fin_training", i32), ("fin_count", f32), ("pad_", i32)]
+                ("fin_dgamma", vp), ("fin_dbeta", vp), ("fin_C", i32), ("fin_training", i32), ("fin_count", f32), ("gn_mode", i32)]
+
+
+class GnBwdFinDesc(C.Structure):
+    _fields_ = [("bstats", vp), ("bcoef", vp), ("gamma", vp), ("dgamma", vp), ("dbeta", vp),
+                ("C", i32), ("Cp", i32), ("N", i32), ("groups", i32), ("count", f32), ("pad_", i32)]
 
 
 class BnBwdFinDesc(C.Structure):
@@ -147,7 +153,7 @@ class Op(C.Structure):
 
 # every symbol include/mfcnet_hip.h declares
 EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_pack_weights", "mfc_conv2d_wgrad", "mfc_conv2d_wgrad_parts", "mfc_conv2d_wgrad_batch", "mfc_unpack_wgrad",
-           "mfc_bn_finalize", "mfc_bn_finalize_batch", "mfc_ws_normalize", "mfc_gn_finalize", "mfc_upsample_nearest2x", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
+           "mfc_bn_finalize", "mfc_bn_finalize_batch", "mfc_ws_normalize", "mfc_gn_finalize", "mfc_upsample_nearest2x", "mfc_gnbwd_finalize", "mfc_ws_backward", "mfc_upsample_nearest2x_bwd", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_bias_grad_slices", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd", "mfc_confusion_counts", "mfc_adam_step", "mfc_adam_step_guarded", "mfc_grad_check", "mfc_program_run", "mfc_program_run_ex", "mfc_wait_detached", "mfc_program_profile", "mfc_graph_capture", "mfc_graph_launch", "mfc_graph_destroy",
            "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect", "mfc_prof_dump"]

@@ -59,15 +59,36 @@ class _MFCFn(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
+class _MFCHeadFn(torch.autograd.Function):
+    """temporal head on externally computed per-frame logits (base_model = "resunet_vb"): the gradient w.r.t. the logits flows on into the
+    per-frame network's own autograd node"""
+    @staticmethod
+    def forward(ctx, logits, anchor, model, plan, flow, depth):
+        ctx.model, ctx.plan = model, plan
+        return plan.run_forward(None, flow, depth, ext_logits=logits)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = ctx.model._run_backward(ctx.plan, gout)
+        return g, None, None, None, None, None
+
+
 class HRNetMultiHIP(nn.Module):
-    """HRNetMultiLarge / HRNetMultiBasic on MI355X (constructor mirrors multiframe_model.py:409,442)."""
+    """HRNetMultiLarge / HRNetMultiBasic on MI355X (constructor mirrors multiframe_model.py:409,442).
+    base_model = "hrnet" (the reference hard-codes HighResolutionNet, multiframe_model.py:414,447) or "resunet_vb": models/resunet.py's
+    ResUnet_VB(channels=3, dim=resunet_dim, out_dim=num_classes) as the per-frame network -- the class the reference ships as the
+    alternative GroupNorm / SiLU base; its parameters are ordinary nn.Parameters under `base_model.` (train them with torch.optim; FlatAdam
+    covers the temporal head's arena), its full-resolution logits feed the same head gather / 4-conv head."""
 
     basic = False
     single = False          # True: single-frame HighResolutionNet (no temporal head), see HighResolutionNetHIP
 
     def __init__(self, num_classes=2, num_frames=1, pretrained=True, loadpath=None, optflow_inputs=False,
-                 depth_inputs=False, width=48, compute_dtype="fp32", fuse_bn=True):
+                 depth_inputs=False, width=48, compute_dtype="fp32", fuse_bn=True, base_model="hrnet", resunet_dim=16):
         super().__init__()
+        if base_model not in ("hrnet", "resunet_vb") or (base_model != "hrnet" and self.single):
+            raise ValueError(f"base_model {base_model!r} not recognized")
+        self.base_kind = base_model
         self.num_classes, self.num_frames = num_classes, num_frames
         self.pretrained = pretrained                      # ignored by the reference too (multiframe_model.py:413)
         self.optflow_inputs, self.depth_inputs = optflow_inputs, depth_inputs
@@ -77,6 +98,8 @@ class HRNetMultiHIP(nn.Module):
         self.parallel_branches = True      # run the independent branches of each HRNet module on parallel HIP streams
         if self.single:
             self._entries: List[Entry] = hrnet_entries(width, num_classes, p="")
+        elif base_model == "resunet_vb":
+            self._entries = head_entries(self.basic, num_classes, num_frames, optflow_inputs, depth_inputs)
         else:
             self._entries = hrnet_entries(width, num_classes) + head_entries(
                 self.basic, num_classes, num_frames, optflow_inputs, depth_inputs)
@@ -96,7 +119,11 @@ class HRNetMultiHIP(nn.Module):
                 nn_ += 1
         self._n_base = np_ if self.single else min(off for n, off in self._poff.items() if n.startswith("multiframe_net."))
         self._np, self._nb, self._nn = np_, nb, nn_
-        self.add_module("base_model", _Node())
+        if base_model == "resunet_vb":
+            from .resunet import ResUnet_VB
+            self.add_module("base_model", ResUnet_VB(channels=3, dim=resunet_dim, out_dim=num_classes, compute_dtype=self.compute_dtype))
+        else:
+            self.add_module("base_model", _Node())
         self.add_module("multiframe_net", _Node())
         self._alloc_flat(torch.device("cpu"))
         self._default_init()
@@ -205,6 +232,7 @@ class HRNetMultiHIP(nn.Module):
         B, c, H, W = frames[0].shape
         if c != 3 or H % 4 or W % 4 or H < 32 or W < 32:
             raise ValueError(f"frames must be [B,3,H,W] with H,W multiples of 4 and >= 32, got {tuple(frames[0].shape)}")
+        ext = self.base_kind == "resunet_vb"
         if (optflow is not None) != bool(self.optflow_inputs) or (depth is not None) != bool(self.depth_inputs):
             raise ValueError("optflow/depth inputs do not match the model's optflow_inputs/depth_inputs")
         if optflow is not None and len(optflow) != self.num_frames - 1:
@@ -213,6 +241,13 @@ class HRNetMultiHIP(nn.Module):
             raise ValueError("depth must hold num_frames tensors")
         need_bwd = torch.is_grad_enabled()
         plan = self._get_plan(B, H, W, optflow is not None, depth is not None, need_bwd, frames[0].device)
+        if ext:
+            # GroupNorm statistics are per image, so the T frames go through the per-frame network as one batch of T*B images
+            # (multiframe_model.py:459-461 calls it frame by frame: the same arithmetic)
+            logits = self.base_model(torch.cat(frames, 0))
+            if need_bwd:
+                return _MFCHeadFn.apply(logits, self._anchor, self, plan, optflow, depth)
+            return plan.run_forward(None, optflow, depth, ext_logits=logits)
         if need_bwd:
             return _MFCFn.apply(self._anchor, self, plan, frames, optflow, depth)
         return plan.run_forward(frames, optflow, depth)
@@ -222,7 +257,7 @@ class HRNetMultiHIP(nn.Module):
         autograd semantics: a parameter whose `.grad` is still set (no zero_grad() since the last backward) ACCUMULATES; one
         whose `.grad` is None gets a fresh gradient.  Parameters with requires_grad=False never get a `.grad` (and when the whole
         per-frame network is frozen its backward is not even computed, see _get_plan)."""
-        named = list(self.named_parameters())
+        named = [(n, p) for n, p in self.named_parameters() if n in self._poff]      # (an external per-frame network keeps its own gradients)
         live = [(n, p) for n, p in named if p.requires_grad and p.grad is not None]
         if live and getattr(self, "grad_bucket_hook", None) is not None:
             raise L.MfcError("gradient accumulation across backward passes cannot be combined with a gradient-bucket hook "
@@ -237,13 +272,14 @@ class HRNetMultiHIP(nn.Module):
                     off = self._poff[n]
                     keep[off:off + p.numel()] = old[off:off + p.numel()]
                 old = keep
-        plan.run_backward(gout)
+        gin = plan.run_backward(gout)
         if old is not None:
             self._G.add_(old)
         for n, p in named:
-            if p.requires_grad and p.grad is None:
+            if p.requires_grad and p.grad is None and n in self._poff:
                 off = self._poff[n]
                 p.grad = self._G[off:off + p.numel()].view(p.shape)
+        return gin
 
     # segments of the flat arenas = the reference's two optimizer groups
     def flat_segments(self):

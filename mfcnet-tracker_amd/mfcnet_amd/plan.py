@@ -149,6 +149,7 @@ class Plan:
         self.T, self.nc, self.width = model.num_frames, model.num_classes, model.width
         self.basic = model.basic
         self.single = getattr(model, "single", False)              # single-frame HighResolutionNet: no temporal head
+        self.ext_base = getattr(model, "base_kind", "hrnet") != "hrnet"      # per-frame logits come from outside (ResUnet_VB): head only
         self.base_prefix = "" if self.single else "base_model."
         self.has_flow, self.has_depth = has_flow, has_depth
         self.dtype = model.compute_dtype
@@ -401,13 +402,24 @@ class Plan:
         self.out_buf = f32(B * nc * H * W)
         self.gout_buf = f32(B * nc * H * W) if self.need_backward else 0
 
-        # ---- input bridge: T NCHW fp32 frames -> one NHWC [T*B, H, W, 8] tensor (multiframe_model.py:459)
-        x0 = self.tensor(T * B, H, W, 3, B, "frames", needs_grad=False)
-        for t in range(T):
-            r = L.RawOp(self.in_frames[t], x0.ptr + t * B * H * W * x0.Cp * self.esz, 0, 0)
-            r.i[0:7] = [self.dtype, B, 3, H, W, x0.Cp, 0]
+        if self.ext_base:
+            # ---- the per-frame network runs outside this plan (ResUnet_VB, its own programs): its FULL-resolution logits [T*B, nc, H, W]
+            #      come in as one NCHW fp32 tensor; the gradient w.r.t. them goes back out the same way
+            self.in_logits = f32(T * B * nc * H * W)
+            self.gin_buf = f32(T * B * nc * H * W) if (self.need_backward and not self.base_frozen) else 0
+            logits = self.tensor(T * B, H, W, nc, B, "ext_logits", needs_grad=not self.base_frozen)
+            r = L.RawOp(self.in_logits, logits.ptr, 0, 0)
+            r.i[0:7] = [self.dtype, T * B, nc, H, W, logits.Cp, 0]
             self.fwd.append((L.OP_NCHW2NHWC, r))
-        logits = self._hrnet(Act(x0))
+            self.ext_logits = logits
+        else:
+            # ---- input bridge: T NCHW fp32 frames -> one NHWC [T*B, H, W, 8] tensor (multiframe_model.py:459)
+            x0 = self.tensor(T * B, H, W, 3, B, "frames", needs_grad=False)
+            for t in range(T):
+                r = L.RawOp(self.in_frames[t], x0.ptr + t * B * H * W * x0.Cp * self.esz, 0, 0)
+                r.i[0:7] = [self.dtype, B, 3, H, W, x0.Cp, 0]
+                self.fwd.append((L.OP_NCHW2NHWC, r))
+            logits = self._hrnet(Act(x0))
         self.n_base_ops = len(self.ops)               # forward graph nodes [0, n_base_ops) belong to the per-frame network
         # ---- head input: x4 up-sample + temporal concat (+flow, +depth, +warp)
         basic_warp = self.basic and self.has_flow
@@ -748,6 +760,11 @@ class Plan:
 
         self._flush_wgrads()
         self.cur_lane = 0
+        if self.ext_base and not self.base_frozen:
+            g = self.grad_of(self.ext_logits)
+            r = L.RawOp(g.ptr, self.gin_buf, 0, 0)
+            r.i[0:6] = [self.dtype, self.T * self.B, self.nc, self.H, self.W, g.Cp]
+            self.bwd.append((L.OP_NHWC2NCHW, r))
 
     # ------------------------------------------------------------------ program arrays
 
@@ -897,10 +914,13 @@ class Plan:
         o = off - a.buf.data_ptr()
         return a.buf[o:o + 4 * n].view(torch.float32).view(shape)
 
-    def run_forward(self, frames, flow, depth):
+    def run_forward(self, frames, flow, depth, ext_logits=None):
         B, T, H, W = self.B, self.T, self.H, self.W
-        for t in range(T):
-            self._io(self.in_frames[t], (B, 3, H, W)).copy_(frames[t])
+        if self.ext_base:
+            self._io(self.in_logits, (T * B, self.nc, H, W)).copy_(ext_logits.detach())
+        else:
+            for t in range(T):
+                self._io(self.in_frames[t], (B, 3, H, W)).copy_(frames[t])
         for i, p in enumerate(self.in_flow):
             self._io(p, (B, 2, H, W)).copy_(flow[i])
         for i, p in enumerate(self.in_depth):
@@ -917,7 +937,7 @@ class Plan:
             rc = L.lib.mfc_program_run(self.bwd_prog, len(self.bwd_prog), L.stream_ptr())
             if rc != 0:
                 raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
-            return
+            return self._ext_grad()
         nseg = len(self.bwd_segments)
         for i, (prog, lo, hi) in enumerate(self.bwd_segments):
             # every segment but the last leaves the detached stream un-joined (the chain does not wait for the weight gradients of the
@@ -930,3 +950,10 @@ class Plan:
                 # gradients [lo, hi) of the flat arena are final for a stream that (1) waits for the current stream and (2) has called
                 # mfc_wait_detached -- dist.GradBucketReducer does both for the stream the all-reduce is ordered after
                 hook(lo, hi)
+        return self._ext_grad()
+
+    def _ext_grad(self):
+        """gradient w.r.t. the externally computed per-frame logits (None when the plan owns the per-frame network or it is frozen)"""
+        if not (self.ext_base and self.need_backward and not self.base_frozen):
+            return None
+        return self._io(self.gin_buf, (self.T * self.B, self.nc, self.H, self.W)).clone()
