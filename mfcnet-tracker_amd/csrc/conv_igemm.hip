@@ -843,6 +843,10 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
 bool ring_eligible(const mfc_conv_desc* d);
 int ring_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
 int ring_launch(const mfc_conv_desc* d, hipStream_t st);
+// conv3x3_stream.hip
+bool stream_eligible(const mfc_conv_desc* d);
+int stream_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
+int stream_launch(const mfc_conv_desc* d, hipStream_t st);
 // conv_gemm1x1.hip
 bool gemm1x1_eligible(const mfc_conv_desc* d);
 int gemm1x1_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
@@ -851,6 +855,7 @@ int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st);
 extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
     if (!d) return MFC_ERR_INVALID_ARG;
     if (out && ring_eligible(d)) return ring_layout(d, out);
+    if (out && stream_eligible(d)) return stream_layout(d, out);
     if (out && gemm1x1_eligible(d)) return gemm1x1_layout(d, out);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     mfc_conv_desc t = *d;
@@ -870,6 +875,7 @@ extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
 extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
     if (!d) return MFC_ERR_INVALID_ARG;
     if (ring_eligible(d)) { mfc_conv_layout l; const int rc = ring_layout(d, &l); return rc < 0 ? rc : l.lds_bytes; }
+    if (stream_eligible(d)) { mfc_conv_layout l; const int rc = stream_layout(d, &l); return rc < 0 ? rc : l.lds_bytes; }
     if (gemm1x1_eligible(d)) { mfc_conv_layout l; gemm1x1_layout(d, &l); return l.lds_bytes; }
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
@@ -931,6 +937,7 @@ static int conv_dispatch(const ConvK& k, int MT, int PM, int NW, size_t lds, int
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
     if (!d) return MFC_ERR_INVALID_ARG;
     if (ring_eligible(d)) return ring_launch(d, (hipStream_t)stream);
+    if (stream_eligible(d)) return stream_launch(d, (hipStream_t)stream);
     const bool fused = d && (d->acc_src || d->bn_y);
     if (d && gemm1x1_eligible(d)) return fused ? MFC_ERR_UNSUPPORTED : gemm1x1_launch(d, (hipStream_t)stream);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;

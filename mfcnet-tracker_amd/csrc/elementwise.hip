@@ -265,7 +265,19 @@ template <typename T>
 __device__ inline uint4 ld_lin(const mfc_view& v, long pix, int ch) {
     return *(const uint4*)((const char*)v.ptr + ((size_t)pix * v.Cp + ch) * sizeof(T));
 }
+// E consecutive floats of a coefficient row as 16-byte vector loads (rows are 32-byte aligned: Cp % 8 == 0, channel offsets % E == 0).
+// Always loaded this way, unconditionally, ahead of the arithmetic: scalar reads of cf[e] inside the arms of a mode switch stop hipcc's
+// vectoriser and make it branch and wait per element (bnbwd_apply_kernel went from 16 dwordx4 loads to 160 dword loads and 7x the time)
+template <int E>
+__device__ inline void ld_coef(const float* p, float* out) {
+#pragma unroll
+    for (int q = 0; q < E / 4; ++q) {
+        const float4 v = *(const float4*)(p + 4 * q);
+        out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+    }
+}
 // masked gradient of one granule: mode 0 -> g, mode 1 -> g * [mask_src > 0], mode 2 -> g * [y*scale+shift > 0]
+// (cf = {scale[E], shift[E]} of the granule's channels, preloaded)
 template <typename T>
 __device__ inline void apply_mask(const mfc_bnbwd_desc& d, const uint4& mraw, const float* yv, const float* cf, float* gm) {
     constexpr int E = Gran<T>::E;
@@ -276,14 +288,14 @@ __device__ inline void apply_mask(const mfc_bnbwd_desc& d, const uint4& mraw, co
         for (int e = 0; e < E; ++e) gm[e] = m[e] > 0.f ? gm[e] : 0.f;
     } else if (d.mask_mode == 2) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) gm[e] = (yv[e] * cf[e] + cf[d.y.Cp + e]) > 0.f ? gm[e] : 0.f;
+        for (int e = 0; e < E; ++e) gm[e] = (yv[e] * cf[e] + cf[E + e]) > 0.f ? gm[e] : 0.f;
     } else if (d.mask_mode == 3) {          // one bit per element, one byte per 8-channel granule (written by mfc_combine_fwd)
 #pragma unroll
         for (int e = 0; e < E; ++e) gm[e] = ((mraw.x >> e) & 1u) ? gm[e] : 0.f;
     } else if (d.mask_mode == 4) {          // SiLU (resunet.py:67): d silu(z) / dz = s (1 + z (1 - s)), s = sigmoid(z), z = y*scale + shift
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const float z = yv[e] * cf[e] + cf[d.y.Cp + e];
+            const float z = yv[e] * cf[e] + cf[E + e];
             const float sg = 1.f / (1.f + __expf(-z));
             gm[e] *= sg * (1.f + z * (1.f - sg));
         }
@@ -302,10 +314,9 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
     float s1[E], s2[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + d.y.c_off + gi * E;
-    float mean[E], rstd[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) { mean[e] = cf[2 * d.y.Cp + e]; rstd[e] = cf[3 * d.y.Cp + e]; }
+    const float* cfp = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + d.y.c_off + gi * E;
+    float mean[E], rstd[E], cf[2 * E];
+    ld_coef<E>(cfp, cf); ld_coef<E>(cfp + d.y.Cp, cf + E); ld_coef<E>(cfp + 2 * d.y.Cp, mean); ld_coef<E>(cfp + 3 * d.y.Cp, rstd);
     const long gbase = (long)grp * pix_per_group;
     const long p0 = (long)blockIdx.x * pix_per_block;
     long p1 = p0 + pix_per_block; if (p1 > pix_per_group) p1 = pix_per_group;
@@ -457,18 +468,22 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long
         if (base + u * 256u >= (unsigned)total) break;
         const int grp = (int)(pix[u] / ppg);
         const int c = d.y.c_off + gq[u] * E;
-        const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + c;
-        const float* bc = d.bcoef + (size_t)grp * 2 * d.y.Cp + c;
+        const float* cfp = (const float*)d.y.coef + (size_t)grp * 4 * d.y.Cp + c;
+        const float* bcp = d.bcoef + (size_t)grp * 2 * d.y.Cp + c;
+        float cf[2 * E], mu[E], rs[E], b1[E], b2[E];
+        ld_coef<E>(cfp, cf); ld_coef<E>(cfp + d.y.Cp, cf + E); ld_coef<E>(cfp + 2 * d.y.Cp, mu); ld_coef<E>(cfp + 3 * d.y.Cp, rs);
+        ld_coef<E>(bcp, b1); ld_coef<E>(bcp + d.y.Cp, b2);
         float yv[E], gm[E], o[E];
         Gran<T>::unpack(yr[u], yv); Gran<T>::unpack(gr[u], gm);
         apply_mask<T>(d, mr[u], yv, cf, gm);
+        // GroupNorm (gn_mode): the two means span the channels of a group, so they are not scaled by the channel's gamma:
+        // dy = gamma rstd g - rstd (A + yhat B), bcoef = A, B of the channel's group (mfc_gnbwd_finalize).  Written as ONE formula
+        // dy = scale * g - k * (b1 + yhat * b2), k = scale (BatchNorm) or rstd (GroupNorm), with every coefficient loaded
+        // unconditionally: loads inside the arms of a select make hipcc branch and wait per element (7x slower, measured)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const float yh = (yv[e] - cf[2 * d.y.Cp + e]) * cf[3 * d.y.Cp + e];
-            // GroupNorm (gn_mode): the two means span the channels of a group, so they are not scaled by the channel's gamma:
-            // dy = gamma rstd g - rstd (A + yhat B), bcoef = A, B of the channel's group (mfc_gnbwd_finalize)
-            o[e] = d.gn_mode ? (cf[e] * gm[e] - cf[3 * d.y.Cp + e] * (bc[e] + yh * bc[d.y.Cp + e]))
-                             : cf[e] * (gm[e] - bc[e] - yh * bc[d.y.Cp + e]);
+            const float yh = (yv[e] - mu[e]) * rs[e];
+            o[e] = d.gn_mode ? (cf[e] * gm[e] - rs[e] * (b1[e] + yh * b2[e])) : cf[e] * (gm[e] - b1[e] - yh * b2[e]);
         }
         *(uint4*)((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(o);
     }
@@ -522,15 +537,17 @@ __global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, 
             if (base + u * 256u >= total) break;
             const int grp = (int)(pix[u] / ppg);
             const int c = d.y.c_off + gq[u] * E;
-            const float* cf = (const float*)d.y.coef + (size_t)grp * 4 * Cp + c;
+            const float* cfp = (const float*)d.y.coef + (size_t)grp * 4 * Cp + c;
             const float* b1 = lbc + (grp * 2 + 0) * Cs + gq[u] * E;
             const float* b2 = lbc + (grp * 2 + 1) * Cs + gq[u] * E;
+            float cf[2 * E], mu[E], rs[E];
+            ld_coef<E>(cfp, cf); ld_coef<E>(cfp + Cp, cf + E); ld_coef<E>(cfp + 2 * Cp, mu); ld_coef<E>(cfp + 3 * Cp, rs);
             float yv[E], gm[E], o[E];
             Gran<T>::unpack(yr[u], yv); Gran<T>::unpack(gr[u], gm);
             apply_mask<T>(d, mr[u], yv, cf, gm);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const float yh = (yv[e] - cf[2 * Cp + e]) * cf[3 * Cp + e];
+                const float yh = (yv[e] - mu[e]) * rs[e];
                 o[e] = cf[e] * (gm[e] - b1[e] - yh * b2[e]);
             }
             *(uint4*)((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(o);
