@@ -55,6 +55,7 @@ def parse_args():
                     help="storage type of activations / packed weights (fp16: IEEE half with a static loss scale, BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no `roofline` object)")
+    ap.add_argument("--no-fp16-line", action="store_true", help="skip the fp16 side measurement of the default bf16 run (`fp16_storage` object)")
     ap.add_argument("--serial", action="store_true", help="one stream: no branch lanes / detached weight-gradient streams (for kernel profiles)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the data-parallel step path even with one rank "
@@ -386,6 +387,45 @@ def main():
         L.lib.mfc_set_flag(9, 0 if args.serial else 3)
         rows = L.prof_collect()
 
+    # ---- the same step with fp16 storage (adaptive loss scale), reported BESIDE the bf16 headline: 16-bit training fidelity is set by the
+    #      forward tensors' rounding (tests/fidelity_probe.py) and fp16 keeps three more mantissa bits there
+    plan = next(iter(getattr(model, "_plans", {}).values()), None)
+    fused_min = records = None
+    if plan is not None and not args.fwd_only:
+        # every convolution input read once and every output written once in the forward pass, x3 for training
+        # (one read of each saved activation and one write + read of each activation gradient), + Adam's 28 B per parameter
+        fused_min = 3 * sum(o[1].t.nbytes + o[2].nbytes for o in plan.ops if o[0] == "conv") + 28 * model._np
+        records = (len(plan.fwd_prog) + len(plan.bwd_prog)) if hasattr(plan, "bwd_prog") else None
+    del plan
+    fp16_side = None
+    if (world == 1 and args.dtype == "bf16" and not args.fwd_only and not args.no_fp16_line and not args.single and not args.serial
+            and not os.environ.get("MFC_SKIP_KINDS")):
+        del model, opt
+        torch.cuda.empty_cache()
+        m16 = cls(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype="fp16",
+                  optflow_inputs=args.optflow, depth_inputs=args.depth).to(device).train()
+        o16 = mfc.FlatAdam(m16, lr=1e-4)
+
+        def step16():
+            return mfc.train_step(m16, o16, frames, mask, optflow=flow, depth=depth)
+        for _ in range(3):
+            step16()
+        n16 = max(5, min(args.steps, 20))
+        e16 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n16)]
+        torch.cuda.synchronize()
+        t16 = time.perf_counter()
+        for a_, b_ in e16:
+            a_.record(); step16(); b_.record()
+        torch.cuda.synchronize()
+        t16 = time.perf_counter() - t16
+        ms16 = sorted(a_.elapsed_time(b_) for a_, b_ in e16)
+        fp16_side = {"value": round(B * T * n16 / t16, 2), "unit": "frames/s", "ms_per_step": round(t16 / n16 * 1e3, 3), "step_ms_median": round(ms16[len(ms16) // 2], 3),
+                     "steps": n16, "loss_scale": float(m16.loss_scaler.scale) if getattr(m16, "loss_scaler", None) else None,
+                     "skipped_steps": o16.skipped_steps(),
+                     "why": "same kernels with IEEE-half storage and an adaptive loss scale; the fidelity of a 16-bit step is set by the rounding of the FORWARD "
+                            "tensors (profiles/r03_fidelity_probe.txt), where fp16 keeps 3 more bits than bf16"}
+        del m16, o16
+
     extra = ("+depth" if args.depth else "") + ("+optflow" if args.optflow else "")
     cfg_label = ("per-GPU share of BASELINE.json configs[3]" if (T, H, W, B, extra) == (3, 480, 640, 4, "+depth+optflow") else
                  "BASELINE.json configs[1]" if (args.single, args.fwd_only, H, W, B) == (True, True, 480, 640, 8) else
@@ -413,12 +453,6 @@ def main():
             flops_step = sum(r["flops"] for r in rows) / prof_steps
             bytes_step = sum(r["bytes"] for r in rows) / prof_steps
             ctr_bytes, ctr_src = pmc_traffic(None, args)
-            plan = next(iter(getattr(model, "_plans", {}).values()), None)
-            fused_min = None
-            if plan is not None and not args.fwd_only:
-                # every convolution input read once and every output written once in the forward pass, x3 for training
-                # (one read of each saved activation and one write + read of each activation gradient), + Adam's 28 B per parameter
-                fused_min = 3 * sum(o[1].t.nbytes + o[2].nbytes for o in plan.ops if o[0] == "conv") + 28 * model._np
             roof.update({
                 "step_frac": round(roof_ms / step_ms, 4),
                 "step": {"ms": round(step_ms, 3), "roof_ms": round(roof_ms, 3),
@@ -430,7 +464,7 @@ def main():
                          "counter_source": ctr_src,
                          "fused_minimum_gb": round(fused_min / 1e9, 2) if fused_min else None,
                          "counters_over_fused_minimum": round(ctr_bytes / fused_min, 2) if (ctr_bytes and fused_min) else None,
-                         "serial_step_ms": round(tot_ms / prof_steps, 3), "records_per_step": (len(plan.fwd_prog) + len(plan.bwd_prog)) if (plan is not None and hasattr(plan, "bwd_prog")) else None},
+                         "serial_step_ms": round(tot_ms / prof_steps, 3), "records_per_step": records},
                 "share_of_profiled_step": round(dom["ms"] / tot_ms, 4), "profiled_step_ms": round(tot_ms / prof_steps, 3),
                 "profiled_steps": prof_steps, "profiled_step_streams": "serial, after the timed region",
                 "families": {f["name"]: {"ms_per_step": round(f["ms"] / prof_steps, 3), "launches": f["launches"] // prof_steps,
@@ -460,6 +494,8 @@ def main():
                           "devices": [f"{h}:cuda{d}" for h, d in devs], "rccl_version": rccl_version(torch) if dist is not None and args.backend == "nccl" else None,
                           "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
                "roofline": roof, "roofline_top": roof_top, "roofline_conv": roof_conv}
+        if fp16_side is not None:
+            out["fp16_storage"] = fp16_side
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width, T, H, W)
         print(json.dumps(out), flush=True)

@@ -26,6 +26,7 @@
 
 int g_conv_ring = 1;
 int g_ring_ablate = 0;
+int g_ring_stagger = 0;
 int g_ring_wgs = 2;                       // workgroups per CU the grid is sized for (tuning: mfc_set_flag(33, n))
 
 struct RingK {
@@ -36,6 +37,7 @@ struct RingK {
     int in_relu, ipg, G, accumulate, bn_mode;
     int tilesY, tilesX, ntiles, per_block;
     int off_coef, off_bnc, off_red;          // LDS byte offsets behind the ring
+    int stagger;                             // cycles the SECOND workgroup of a CU waits before it starts (de-phases the two; mfc_set_flag(37, cycles))
     int ablate;                              // tuning only (mfc_set_flag(32, mask)): 1 skip MFMAs, 2 skip stores, 4 skip DMA, 8 skip fix-up, 16 skip statistics
 };
 
@@ -94,6 +96,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
     if (nun <= 0) return;
     const int H = p.H, W = p.W;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    if (p.stagger > 0) {
+        // Two workgroups share a CU and start together: left alone they issue their DMA, run their MFMAs and store their tiles in the
+        // same phase.  The one in the odd wave slot of its SIMDs (HW_ID.wave_id bit 0: speed only, never correctness) starts late.
+        const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));      // HW_REG_HW_ID, bits [3:0] = wave slot
+        if (hwid & 1u) for (int t = 0; t < p.stagger; t += 1024) __builtin_amdgcn_s_sleep(16);
+    }
 
     // ---------------- tile cursors (tracked incrementally) ----------------
     struct TC { int n, tyi, txi; };
@@ -541,7 +549,7 @@ static int ring_setup(const mfc_conv_desc* d, RingK& k, size_t& lds, int& grid, 
     k.N = d->N; k.H = d->Hout; k.W = d->Wout; k.C = d->Cin;
     k.in_relu = d->in_relu; k.ipg = d->images_per_group; k.G = d->N / d->images_per_group; k.accumulate = d->accumulate; k.bn_mode = d->bn_mask_mode;
     MT = g_ring_mt;
-    k.ablate = g_ring_ablate;
+    k.ablate = g_ring_ablate; k.stagger = g_ring_stagger;
     if (d->Cin == 32) { if (MT == 4) ring_geo<1, 4>(d, k, lds, grid); else ring_geo<1, 2>(d, k, lds, grid); }
     else { MT = 4; ring_geo<2, 4>(d, k, lds, grid); }
     return MFC_OK;
