@@ -43,14 +43,22 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "frames/s" and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 2 * 3 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
-    for rf in (d["roofline"], d["roofline_conv"]):
+    for rf in (d["roofline"], d["roofline_top"], d["roofline_conv"]):
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"):
             assert k in rf, k
         assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    # `roofline` is the row with the largest total time of the profiled step, whatever family it belongs to
-    top = d["roofline"]["top5"]
-    assert top[0]["kernel"] == d["roofline"]["kernel"] and all(top[i]["ms_per_step"] >= top[i + 1]["ms_per_step"] for i in range(len(top) - 1))
-    assert d["roofline_conv"]["kernel"].startswith("conv_igemm_kernel<")
+    # `roofline` is the template FAMILY with the largest total time of the profiled step and carries the whole-step figures;
+    # `roofline_top` is the single instantiation with the largest total time (the first of `top5`)
+    rf = d["roofline"]
+    assert "instantiations of one template" in rf["kernel"] and rf["kernel"].split("<")[0] == next(iter(rf["families"]))
+    assert 0.0 < rf["step_frac"] < 1.0 and abs(rf["step_frac"] - rf["step"]["roof_ms"] / rf["step"]["ms"]) < 2e-3
+    for k in ("mfma_frac", "hbm_frac_algorithmic", "fused_minimum_gb", "records_per_step", "serial_step_ms"):
+        assert k in rf["step"], k
+    top = rf["top5"]
+    assert top[0]["kernel"] == d["roofline_top"]["kernel"] and all(top[i]["ms_per_step"] >= top[i + 1]["ms_per_step"] for i in range(len(top) - 1))
+    assert d["roofline_conv"]["kernel"].startswith(("conv_igemm_kernel<", "conv3x3_ring_kernel<"))
+    assert d["step_ms"]["n"] == 3 and d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
+    assert d["fp16_storage"]["value"] > 0 and d["fp16_storage"]["skipped_steps"] >= 0
     assert d["roofline"]["profiled_step_streams"].startswith("serial")
     assert 0.0 < d["config"]["final_loss"] < 20.0
     assert d["config"]["launcher"] == "bench.py" and d["config"]["ranks"] == 1
