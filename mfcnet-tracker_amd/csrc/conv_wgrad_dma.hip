@@ -18,6 +18,7 @@
 #include "common.h"
 #include <cstdlib>
 
+int g_wgrad_dma_xf8 = 0;             // mfc_set_flag(38, 1): 8-wave workgroups for the launches with an input transform (faster alone, slower in the step: see DESIGN.md)
 int g_wgrad_dma = 1;                 // mfc_set_flag(29, v): 0 = register-staged wave kernel (conv_wgrad.hip) for these launches
 extern int g_wgrad_blocks;           // target workgroups per launch (conv_wgrad.hip, mfc_set_flag(11))
 
@@ -45,14 +46,18 @@ __device__ inline void wd_dma(const char* base, unsigned voff, unsigned lds) {
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds) : "memory");
 }
 
-template <typename TE, bool XF>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(WgradD p) {
+// NW = waves per workgroup.  4: two workgroups fit a CU.  8 (input-transform variant): the in-LDS BatchNorm + ReLU of a sub-tile is VALU /
+// LDS work of the wave that is about to multiply it, and with one wave per SIMD nothing runs under it (27.9 vs 18.7 us at 256
+// workgroups); eight self-contained waves = two per SIMD let one wave's transform issue under the other's MFMAs without doubling the
+// number of workgroups, i.e. of partial-sum slices the unpack has to add.
+template <typename TE, bool XF, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kernel(WgradD p) {
     typedef TE T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* wbase = smem + wave * WD_WAVE;
-    float* coefs = (float*)(smem + 4 * WD_WAVE);          // [G][2][32] scale / shift of this block's input channels
+    float* coefs = (float*)(smem + NW * WD_WAVE);          // [G][2][32] scale / shift of this block's input channels
     // 1-D grid, weight block fastest, XCD-contiguous (conv_wgrad.hip): the workgroups that walk the SAME pixel tiles run on one XCD
     const int Ytot = p.co_blocks * p.ci_blocks;
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(WgradD p) {
     const int ib = y % p.ci_blocks, cb = y / p.ci_blocks;
     const int co0 = cb * 32, ci0 = ib * 32;
     if constexpr (XF) {
-        for (int i = tid; i < p.G * 64; i += 256) {
+        for (int i = tid; i < p.G * 64; i += NW * 64) {
             const int ch = i & 31, w = (i >> 5) & 1, g = i >> 6;
             coefs[i] = (ci0 + ch < p.Cin_p) ? p.in_coef[((size_t)g * 4 + w) * p.Cin_p + ci0 + ch] : 0.f;
         }
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(WgradD p) {
             for (int j = 0; j < 2; ++j) acc[b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // tile coordinates, tracked incrementally (stride decomposed once)
-    const int stride = p.splits * 4;
+    const int stride = p.splits * NW;
     const int st_x = stride % p.tilesX, st_y = (stride / p.tilesX) % p.tilesY, st_n = stride / (p.tilesX * p.tilesY);
     struct TC { int n, tyi, txi; };
     auto tc_next = [&](TC c) {
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(WgradD p) {
     };
 
     if constexpr (XF) __syncthreads();             // coefficient table visible
-    int tile = bsplit * 4 + wave;
+    int tile = bsplit * NW + wave;
     TC t0;
     { t0.txi = tile % p.tilesX; const int q = tile / p.tilesX; t0.tyi = q % p.tilesY; t0.n = q / p.tilesY; }
     TC t1 = tc_next(t0), t2 = tc_next(t1);
@@ -238,10 +243,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(WgradD p) {
         t0 = t1; t1 = t2; t2 = tc_next(t2);
         if (++slot == WD_NST) slot = 0;
     }
-    // ---- tree-reduce the four waves' accumulators through LDS, then one wave stores the slice ----
+    // ---- tree-reduce the waves' accumulators through LDS, then one wave stores the slice ----
     constexpr int NTW = 36;
     bool flusher = true;
-    for (int half = 2; half >= 1; half >>= 1) {
+    for (int half = NW / 2; half >= 1; half >>= 1) {
         __syncthreads();
         const bool dump = flusher && wave >= half && wave < 2 * half;
         const bool take = flusher && wave < half;
@@ -317,25 +322,31 @@ int wgrad_dma_parts(const mfc_wgrad_desc* d) { WgradD f; wgrad_dma_setup(d, f); 
 int wgrad_dma_launch(const mfc_wgrad_desc* d, hipStream_t st) {
     WgradD f; wgrad_dma_setup(d, f);
     const bool xf = d->in_coef != nullptr;
-    const size_t lds = (size_t)4 * WD_WAVE + (xf ? (size_t)f.G * 64 * 4 : 0);
+    const int nw = (xf && g_wgrad_dma_xf8) ? 8 : 4;
+    const size_t lds = (size_t)nw * WD_WAVE + (xf ? (size_t)f.G * 64 * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<bf16_t, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<bf16_t, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<bf16_t, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<f16_t, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<f16_t, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<f16_t, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * f.N * f.H * f.W * (double)f.Co16 * f.Ci16 * 9.0;
         const double bytes = ((double)f.N * f.H * f.W * (f.Cin_p + f.Cout_p)) * 2.0;
         const bool h = d->dtype == MFC_F16;
-        mfc_prof_before(st, h ? (xf ? "conv_wgrad_dma_kernel<_Float16, true>" : "conv_wgrad_dma_kernel<_Float16, false>")
-                              : (xf ? "conv_wgrad_dma_kernel<__bf16, true>" : "conv_wgrad_dma_kernel<__bf16, false>"), flops, bytes);
+        // (the profiler keeps the pointer: literals only)
+        const char* pname = h ? (xf ? (nw == 8 ? "conv_wgrad_dma_kernel<_Float16, true, 8>" : "conv_wgrad_dma_kernel<_Float16, true, 4>") : "conv_wgrad_dma_kernel<_Float16, false, 4>")
+                              : (xf ? (nw == 8 ? "conv_wgrad_dma_kernel<__bf16, true, 8>" : "conv_wgrad_dma_kernel<__bf16, true, 4>") : "conv_wgrad_dma_kernel<__bf16, false, 4>");
+        mfc_prof_before(st, pname, flops, bytes);
     }
     const int grid = f.splits * f.co_blocks * f.ci_blocks;
-    if (xf) MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, true>), dim3(grid), dim3(256), lds, st, f));
-    else MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, false>), dim3(grid), dim3(256), lds, st, f));
+    if (xf && nw == 8) MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, true, 8>), dim3(grid), dim3(512), lds, st, f));
+    else if (xf) MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, true, 4>), dim3(grid), dim3(256), lds, st, f));
+    else MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, false, 4>), dim3(grid), dim3(256), lds, st, f));
     if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;

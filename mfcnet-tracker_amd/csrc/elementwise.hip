@@ -489,14 +489,33 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long
     }
 }
 
-// apply with the finalize fused in: persistent workgroups; prologue = replica sums -> c1, c2 in LDS (and dgamma / dbeta from
-// workgroup 0); then the same element-wise pass over chunks of 1024 granules
+// apply with the finalize fused in: prologue = replica sums -> c1, c2 in LDS (and dgamma / dbeta from workgroup 0); then the same
+// element-wise pass.  Every workgroup owns ONE contiguous range of `per_block` granules (a multiple of 8 = whole 128-byte lines; equal
+// ranges, so the 4 workgroups of every CU finish together -- with chunks dealt round-robin some workgroups had 2 chunks and some 1),
+// and the loads of its first 1024 granules are issued BEFORE the prologue, whose dependent fp64 replica reads (2-3 us of latency at
+// the head of a 10-25 us launch) then run under them.
 template <typename T>
-__global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, unsigned total, int Cg, int G, unsigned nchunks) {
+__global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, unsigned total, int Cg, int G, unsigned per_block) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 4;
     __shared__ float lbc[8 * 2 * 128];               // [g][stat][c] (G <= 8, C <= 128): c1 = mean(g*m), c2 = mean(g*m*yhat)
     const int Cs = Cg * E, Cp = d.y.Cp;
+    const unsigned lo = blockIdx.x * per_block;
+    const unsigned hi = (lo + per_block < total) ? lo + per_block : total;          // (host: grid * per_block >= total, lo < total)
+    uint4 yr[U], gr[U], mr[U]; unsigned pix[U]; int gq[U];
+    auto load = [&](unsigned base) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            unsigned idx = base + u * 256u;
+            if (idx >= hi) idx = hi - 1;             // clamp: branch-free loads, masked at the store
+            pix[u] = idx / (unsigned)Cg; gq[u] = (int)(idx - pix[u] * (unsigned)Cg);
+            yr[u] = ld_lin<T>(d.y, pix[u], d.y.c_off + gq[u] * E);
+            gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
+            if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
+            else if (d.mask_mode == 3) mr[u].x = ld_bits(d.mask, pix[u], d.mask.c_off + gq[u] * E);
+        }
+    };
+    load(lo + threadIdx.x);
     const size_t rstride = (size_t)G * 2 * Cp;
     for (int i = threadIdx.x; i < G * 2 * Cs; i += 256) {
         const int c = i % Cs, gs = i / Cs;            // gs = g*2 + stat
@@ -513,28 +532,14 @@ __global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, 
         }
         __syncthreads();
     }
-    const float inv = d.fin_training ? 1.0f / d.fin_count : 0.f;
     for (int i = threadIdx.x; i < G * 2 * Cs; i += 256)
         lbc[i] = d.fin_training ? (float)((double)lbc[i] / (double)d.fin_count) : 0.f;
-    (void)inv;
     __syncthreads();
     const unsigned ppg = (unsigned)d.images_per_group * d.y.H * d.y.W;
-    for (unsigned chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const unsigned base = (chunk * 256u) * U + threadIdx.x;
-        uint4 yr[U], gr[U], mr[U]; unsigned pix[U]; int gq[U];
+    for (unsigned base = lo + threadIdx.x; ; ) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            unsigned idx = base + u * 256u;
-            if (idx >= total) idx = total - 1;
-            pix[u] = idx / (unsigned)Cg; gq[u] = (int)(idx - pix[u] * (unsigned)Cg);
-            yr[u] = ld_lin<T>(d.y, pix[u], d.y.c_off + gq[u] * E);
-            gr[u] = ld_lin<T>(d.g, pix[u], d.g.c_off + gq[u] * E);
-            if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, pix[u], d.mask.c_off + gq[u] * E);
-            else if (d.mask_mode == 3) mr[u].x = ld_bits(d.mask, pix[u], d.mask.c_off + gq[u] * E);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (base + u * 256u >= total) break;
+            if (base + u * 256u >= hi) break;
             const int grp = (int)(pix[u] / ppg);
             const int c = d.y.c_off + gq[u] * E;
             const float* cfp = (const float*)d.y.coef + (size_t)grp * 4 * Cp + c;
@@ -552,6 +557,9 @@ __global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, 
             }
             *(uint4*)((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(o);
         }
+        base += 256u * U;
+        if (base - threadIdx.x >= hi) break;          // (block-uniform)
+        load(base);
     }
 }
 
@@ -566,10 +574,12 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
         const long tot = (long)d->N * d->y.H * d->y.W * Cgf;
         if (tot >= (1L << 31) - 2048) return MFC_ERR_UNSUPPORTED;
         const unsigned nchunks = (unsigned)((tot + 1023) / 1024);
-        const int grid = nchunks < 1024u ? (int)nchunks : 1024;
+        int grid = nchunks < 1024u ? (int)nchunks : 1024;
+        unsigned per_block = (unsigned)(((tot + grid - 1) / grid + 7) / 8 * 8);
+        grid = (int)((tot + per_block - 1) / per_block);
         hipStream_t s2 = (hipStream_t)stream;
         EW_PROF(s2, "bnbwd_apply_fin_kernel", d->dtype, (double)tot * 16.0 * (3 + (d->mask_mode == 1 ? 1 : 0)) + (d->mask_mode == 3 ? (double)tot : 0.0));
-        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_apply_fin_kernel<T_>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, nchunks));
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_apply_fin_kernel<T_>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, per_block));
         MFC_PROF_END(s2);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
