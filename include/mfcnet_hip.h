@@ -117,6 +117,12 @@ typedef struct {
     int32_t bn_mask_mode;
     int32_t flags;           /* bit 0 (MFC_CONV_WANT_FA): restrict the geometry search to launches that support the fusions above (fa = 1) when one
                               * exists -- set it BEFORE mfc_conv2d_layout / packing, so that the packed weight image matches the launch */
+    /* ---- optional: BatchNorm finalize of the PRODUCER folded into this launch (round 3).  in_fin = DEVICE pointer to the mfc_bnfin_desc
+     * whose `coef` is this launch's in_coef: every workgroup first turns the statistic sums into the coefficient block itself (identical
+     * values, written redundantly; the replica reads run under the launch's own first loads) and workgroup 0 updates the running
+     * statistics -- the one-block mfc_bn_finalize launch between producer and consumer (~3.7 us of dependent launch) disappears.
+     * Training-mode descriptors only; launches that cannot take an input transform return MFC_ERR_UNSUPPORTED. */
+    const void* in_fin;
 } mfc_conv_desc;
 #define MFC_CONV_WANT_FA 1
 int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream);
@@ -240,6 +246,8 @@ typedef struct {
     int32_t images_per_group;
     uint64_t maskbits;       /* optional (bf16): uint8 [N*H*W*out.Cp/8], bit e of byte (pixel*Cp + c)/8 = out[pixel][c + e] > 0 -- the
                               * ReLU mask the BatchNorm backward of the summed terms reads (mask_mode 3) instead of the whole tensor */
+    uint64_t fin;            /* optional: DEVICE pointer to the mfc_bnfin_desc (training mode, at most 128 channels) of ONE source's BatchNorm, folded into
+                              * this launch as in mfc_conv_desc.in_fin: its `coef` must be that source's view.coef */
 } mfc_combine_desc;
 int mfc_combine_fwd(const mfc_combine_desc* d, void* stream);
 

@@ -477,6 +477,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stream_kernel(StreamK p) {    
 // ------------------------------------------------------------------------------------------
 static bool stream_fits(const mfc_conv_desc* d);
 bool stream_eligible(const mfc_conv_desc* d) {
+    if (d && d->in_fin) return false;                            // (the folded finalize is built into conv_igemm / conv3x3_ring only)
     if (!g_conv_stream || !d || !mfc_is16(d->dtype)) return false;
     if (d->TA != 3 || d->TB != 3 || d->dh0 != -1 || d->dw0 != -1 || d->in_stride != 1) return false;
     if (d->out_sh != 1 || d->out_sw != 1 || d->out_oh != 0 || d->out_ow != 0) return false;

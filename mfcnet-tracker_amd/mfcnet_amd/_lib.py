@@ -48,7 +48,8 @@ class ConvDesc(C.Structure):
                 ("TA", i32), ("TB", i32), ("dh0", i32), ("dw0", i32), ("in_stride", i32),
                 ("out_sh", i32), ("out_sw", i32), ("out_oh", i32), ("out_ow", i32),
                 ("in_relu", i32), ("images_per_group", i32), ("accumulate", i32), ("TH", i32), ("TW", i32),
-                ("acc_src", vp), ("bn_y", vp), ("bn_coef", vp), ("bn_bits", vp), ("bn_mask_mode", i32), ("flags", i32)]
+                ("acc_src", vp), ("bn_y", vp), ("bn_coef", vp), ("bn_bits", vp), ("bn_mask_mode", i32), ("flags", i32),
+                ("in_fin", vp)]
 
 
 class PackJob(C.Structure):
@@ -94,7 +95,7 @@ class View(C.Structure):
 
 class CombineDesc(C.Structure):
     _fields_ = [("out", View), ("src", View * 4), ("nsrc", i32), ("relu", i32), ("dtype", i32),
-                ("N", i32), ("C", i32), ("images_per_group", i32), ("maskbits", u64)]
+                ("N", i32), ("C", i32), ("images_per_group", i32), ("maskbits", u64), ("fin", u64)]
 
 
 class BnBwdDesc(C.Structure):
