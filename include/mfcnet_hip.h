@@ -534,7 +534,14 @@ int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the 
  *  26  wgrad: smallest Cin and Cout sent to that GEMM (64)           27  BN-backward reduce: workgroups per launch (1024; 512-2048 measured equal)
  *  28  program: defer the final join of the detached stream to the next program (0; tuning only -- the product path passes
  *      MFC_RUN_DEFER_JOIN to mfc_program_run_ex instead)
- *  29  wgrad: 3x3 / stride-1 weight gradients of 32-channel-multiple layers through the LDS-DMA ring kernel (conv_wgrad_dma.hip) (1) */
+ *  29  wgrad: 3x3 / stride-1 weight gradients of 32-channel-multiple layers through the LDS-DMA ring kernel (conv_wgrad_dma.hip) (1)
+ *  30  conv: 32 -> 32 / 64 -> 64 3x3 stride-1 convolutions through the register-resident-weight ring kernel (conv3x3_ring.hip) (1)
+ *  31  ring kernel: 16-pixel rows per wave (4; 2)    32  ring kernel: ablation mask (0)             33  ring kernel: workgroups per CU (2)
+ *  34  conv: 128 / 256-channel 3x3 through the two-ring stream kernel (conv3x3_stream.hip) (0: correct but slower, see its header)
+ *  35  stream kernel: ablation mask (0)              36  stream kernel: force form 10 * MSH + MT (0)
+ *  37  ring kernel: start delay of the workgroup in the odd wave slot of a CU (0; no effect measured)
+ *  38  wgrad DMA kernel: 8 waves per workgroup for launches with an input transform (0: faster alone, slower in the step)
+ *  39  fused BatchNorm-backward finalize + apply: workgroups per launch (1024; 2048 / 4096 measured slower) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

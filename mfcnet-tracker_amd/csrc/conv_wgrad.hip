@@ -42,7 +42,7 @@ int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
-extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma, g_conv_ring, g_ring_ablate, g_ring_wgs, g_conv_stream, g_stream_ablate, g_ring_stagger, g_wgrad_dma_xf8, g_applyfin_blocks;
+extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma, g_conv_ring, g_ring_ablate, g_ring_wgs, g_conv_stream, g_stream_ablate, g_ring_stagger, g_wgrad_dma_xf8, g_applyfin_blocks, g_ew_ablate, g_bnred_threads, g_bnred_minpx;
 int mfc_stream_set_mt(int v);
 int mfc_ring_set_mt(int v);
 extern "C" int mfc_set_flag(int id, int value) {
@@ -84,6 +84,9 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 37) { g_ring_stagger = value; return 0; }
     if (id == 38) { g_wgrad_dma_xf8 = value; return 0; }
     if (id == 39) { g_applyfin_blocks = value > 0 ? value : 1024; return 0; }
+    if (id == 40) { g_ew_ablate = value; return 0; }
+    if (id == 41) { g_bnred_threads = value; return 0; }
+    if (id == 42) { g_bnred_minpx = value > 0 ? value : 8; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }

@@ -387,11 +387,11 @@ __device__ inline void apply_mask(const mfc_bnbwd_desc& d, const uint4& mraw, co
 // the byte of mask bits of granule (pixel, channel c) of a [.., Cp] tensor
 __device__ inline unsigned ld_bits(const mfc_view& v, long pix, int c) { return ((const unsigned char*)v.ptr)[((size_t)pix * v.Cp + c) >> 3]; }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int Cg, int PPI, int pix_per_block, long pix_per_group) {
+template <typename T, int BS>
+__global__ __launch_bounds__(BS) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int Cg, int PPI, int pix_per_block, long pix_per_group, int ablate) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 4;                       // pixels in flight per thread
-    __shared__ float red[256 * 8 * 2];
+    extern __shared__ float red[];             // [2 E][BS] partial sums of the block's threads
     const int grp = blockIdx.y;
     const int gi = threadIdx.x % Cg, prow = threadIdx.x / Cg;
     float s1[E], s2[E];
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
             yr[u] = ld_lin<T>(d.y, gbase + qq, ych);
             gr[u] = ld_lin<T>(d.g, gbase + qq, gch);
             if (d.mask_mode == 1) mr[u] = ld_lin<T>(d.mask, gbase + qq, mch);
-            else if (d.mask_mode == 3) mr[u].x = ld_bits(d.mask, gbase + qq, mch);
+            else if (d.mask_mode == 3) mr[u].x = (ablate & 4) ? 0xffu : ld_bits(d.mask, gbase + qq, mch);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
                 apply_mask<T>(d, mr[u], yv, cf, gm);
 #pragma unroll
                 for (int e = 0; e < E; ++e) { s1[e] += gm[e]; s2[e] += gm[e] * (yv[e] - mean[e]) * rstd[e]; }
-                if (d.dy.ptr) {          // masked gradient for the identity branch of the same sum
+                if (d.dy.ptr && !(ablate & 2)) {          // masked gradient for the identity branch of the same sum
                     char* o = (char*)d.dy.ptr + ((size_t)(gbase + pp + (long)u * PPI) * d.dy.Cp + d.dy.c_off + gi * E) * sizeof(T);
                     if (d.accumulate) {
                         float old[E];
@@ -436,28 +436,34 @@ __global__ __launch_bounds__(256) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int
             }
         }
     }
-    // tree reduction over the pixel rows of the block (all threads take part), then one atomic per (stat, channel)
+    // block reduction over the pixel rows, then one atomic per (stat, channel): every thread parks its 2 E partial sums in LDS, ONE barrier,
+    // and thread (k, g2) adds the PPI values of its column in a fixed order (round 3: the seven-barrier tree this replaces cost 3.5 us
+    // of a 17-38 us launch, profiles/r03_bnbwd_reduce_ablation.txt)
+    if (ablate & 1) { if (s1[0] == 123.f) d.bstats[0] = 1.0; return; }
 #pragma unroll
-    for (int e = 0; e < E; ++e) { red[(e * 2 + 0) * 256 + threadIdx.x] = s1[e]; red[(e * 2 + 1) * 256 + threadIdx.x] = s2[e]; }
+    for (int e = 0; e < E; ++e) { red[(e * 2 + 0) * BS + threadIdx.x] = s1[e]; red[(e * 2 + 1) * BS + threadIdx.x] = s2[e]; }
     __syncthreads();
-    for (int n = PPI; n > 1;) {
-        const int half = (n + 1) >> 1;
-        if (prow + half < n) {
-#pragma unroll
-            for (int k = 0; k < 2 * E; ++k) red[k * 256 + threadIdx.x] += red[k * 256 + threadIdx.x + half * Cg];
-        }
-        n = half;
-        __syncthreads();
-    }
+    if (ablate & 8) { if (red[threadIdx.x] == 123.f) d.bstats[0] = 1.0; return; }
     for (int i = threadIdx.x; i < 2 * E * Cg; i += blockDim.x) {
         const int k = i / Cg, g2 = i - k * Cg;        // k = e*2 + stat
-        const int rep = blockIdx.x % MFC_R;
+        const float* col = red + k * BS + g2;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = 0;
+        for (; r + 4 <= PPI; r += 4) { a0 += col[r * Cg]; a1 += col[(r + 1) * Cg]; a2 += col[(r + 2) * Cg]; a3 += col[(r + 3) * Cg]; }
+        for (; r < PPI; ++r) a0 += col[r * Cg];
+        const float tot = (a0 + a1) + (a2 + a3);
         const int G = gridDim.y;
         const int c = d.y.c_off + g2 * E + (k >> 1);
-        atomicAdd(d.bstats + (((size_t)rep * G + grp) * 2 + (k & 1)) * d.y.Cp + c, (mfc_stat_t)red[k * 256 + g2]);
+        const int rep = blockIdx.x % MFC_R;
+        // (fp64 atomics execute at the memory side whatever their scope, MI355X_MICROARCH.md "Global float atomics": ~1.2 us of drain per
+        //  launch plus the issue of 2 E Cg of them per workgroup; an XCD-local variant has nothing to gain)
+        atomicAdd(d.bstats + (((size_t)rep * G + grp) * 2 + (k & 1)) * d.y.Cp + c, (mfc_stat_t)tot);
     }
 }
 
+int g_bnred_minpx = 8;               // fewest pixels per thread of a BN-backward reduce launch (fewer, longer workgroups on small tensors); mfc_set_flag(42, n)
+int g_bnred_threads = 256;          // threads per workgroup of a BN-backward reduce launch (256; 512 / 1024 measured slower); tuning: mfc_set_flag(41, n)
+int g_ew_ablate = 0;                 // tuning only: mfc_set_flag(40, mask) -- bnbwd_reduce: 1 no block reduction / atomics, 2 no masked-gradient store, 4 no mask-bit loads
 int g_applyfin_blocks = 1024;        // workgroups of a fused finalize + apply launch; tuning: mfc_set_flag(39, n)
 int g_bnred_blocks = 1024;           // workgroups of a BN-backward reduce launch; tuning: mfc_set_flag(27, n)
 static int bnbwd_check(const mfc_bnbwd_desc* d, int& E) {
@@ -478,10 +484,16 @@ extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
     if (d->dy.ptr && (!view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W)) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     if (Cg > 256) return MFC_ERR_UNSUPPORTED;
-    const int PPI = 256 / Cg;
+    // The launch ends with one fp64 atomic per workgroup, statistic and channel, and the atomics on one cell run one after the other at the
+    // memory side (the XCDs' L2s are not coherent): ablation (profiles/r03_bnbwd_reduce_ablation.txt) puts that tail at ~4 us of a 17-38 us
+    // launch, next to ~3.5 us for the old seven-barrier LDS tree.  Larger workgroups (512 / 1024 threads, flag 41) cut the atomics but lose
+    // more in the streaming phase (158 VGPRs: 1024 threads spill); small tensors get fewer, longer workgroups instead (flag 42)
+    const int BS = g_bnred_threads >= 1024 ? 1024 : (g_bnred_threads >= 512 ? 512 : 256);
+    const int PPI = BS / Cg;
     const int G = d->N / d->images_per_group;
     const long ppg = (long)d->images_per_group * d->y.H * d->y.W;
-    long want = ppg / (8L * PPI) + 1; if (want > g_bnred_blocks / G + 1) want = g_bnred_blocks / G + 1;   // blocks per group (~1024 in total, >= 8 pixels per thread)
+    const int nblk = g_bnred_blocks * 256 / BS;
+    long want = ppg / ((long)g_bnred_minpx * PPI) + 1; if (want > nblk / G + 1) want = nblk / G + 1;   // blocks per group (>= g_bnred_minpx pixels per thread)
     int ppb = (int)((ppg + want - 1) / want);
     ppb = ((ppb + PPI - 1) / PPI) * PPI;
     const int bx = (int)((ppg + ppb - 1) / ppb);
@@ -491,7 +503,19 @@ extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
         const double t = (double)d->N * d->y.H * d->y.W * d->C * esz;         // one tensor
         EW_PROF(st, "bnbwd_reduce_kernel", d->dtype, t * (2 + (d->mask_mode == 1 ? 1 : 0) + (d->dy.ptr ? (d->accumulate ? 2 : 1) : 0)) + (d->mask_mode == 3 ? t / 16 : 0));
     }
-    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_reduce_kernel<T_>, dim3(bx, G), dim3(Cg * PPI), 0, st, *d, Cg, PPI, ppb, ppg));
+    const size_t lds = (size_t)2 * E * BS * sizeof(float);
+#define RED_LAUNCH(BS_) do { \
+        static bool attr_set = false; \
+        if (!attr_set) { \
+            (void)hipFuncSetAttribute((const void*)bnbwd_reduce_kernel<float, BS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+            (void)hipFuncSetAttribute((const void*)bnbwd_reduce_kernel<bf16_t, BS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+            (void)hipFuncSetAttribute((const void*)bnbwd_reduce_kernel<f16_t, BS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+            attr_set = true; \
+        } \
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL((bnbwd_reduce_kernel<T_, BS_>), dim3(bx, G), dim3(Cg * PPI), lds, st, *d, Cg, PPI, ppb, ppg, g_ew_ablate)); \
+    } while (0)
+    if (BS == 1024) RED_LAUNCH(1024); else if (BS == 512) RED_LAUNCH(512); else RED_LAUNCH(256);
+#undef RED_LAUNCH
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
