@@ -107,13 +107,14 @@ def pmc_avg(db_path, counter):
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+    outdir = os.environ.get("MFC_PROFILES_DIR") or os.path.join(root, "profiles")      # (on the GPU box: somewhere under gpurun_out/, which travels back)
+    os.makedirs(outdir, exist_ok=True)
     for mode in ("serial", "lanes"):
         p = os.path.join(src, mode, f"{mode}_results.db")
         if not os.path.exists(p):
             continue
         st = kernel_stats(p)
-        with open(os.path.join(root, "profiles", f"{tag}_kernel_stats_{mode}.csv"), "w", newline="") as f:
+        with open(os.path.join(outdir, f"{tag}_kernel_stats_{mode}.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(st[0].keys()))
             w.writeheader(); w.writerows(st)
         print(mode, "top kernels:")
@@ -133,7 +134,7 @@ def main():
             out["kernels"][n] = {"dispatches": calls, "mfma_busy_cycles": round(v), "sq_busy_cycles": round(sq), "grbm_gui_active": round(gui),
                                  "mfma_util": round(v / (gui / 8.0 * 1024.0), 4) if gui else None,
                                  "mfma_busy_over_sq_busy": round(v / sq, 4) if sq else None}
-        with open(os.path.join(root, "profiles", f"{tag}_pmc_mfma.json"), "w") as f:
+        with open(os.path.join(outdir, f"{tag}_pmc_mfma.json"), "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
         for n in sorted(out["kernels"], key=lambda k: -out["kernels"][k]["mfma_busy_cycles"] * out["kernels"][k]["dispatches"])[:8]:
             k = out["kernels"][n]
@@ -154,7 +155,7 @@ def main():
                 step_bytes += (2.0 * f_kb + w_kb) * 1024.0 * calls
         out["step"] = {"steps_in_run": nsteps, "hbm_bytes_per_step": round(step_bytes / nsteps),
                        "note": "counter bytes of every kernel of the run except model set-up (copies, fills, weight packing), divided by the steps of the run"}
-        with open(os.path.join(root, "profiles", f"{tag}_pmc_traffic.json"), "w") as f:
+        with open(os.path.join(outdir, f"{tag}_pmc_traffic.json"), "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
         for n in sorted(out["kernels"], key=lambda k: -out["kernels"][k]["hbm_bytes_per_launch"] * out["kernels"][k]["dispatches"])[:8]:
             k = out["kernels"][n]
