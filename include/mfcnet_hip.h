@@ -541,7 +541,10 @@ int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the 
  *  35  stream kernel: ablation mask (0)              36  stream kernel: force form 10 * MSH + MT (0)
  *  37  ring kernel: start delay of the workgroup in the odd wave slot of a CU (0; no effect measured)
  *  38  wgrad DMA kernel: 8 waves per workgroup for launches with an input transform (0: faster alone, slower in the step)
- *  39  fused BatchNorm-backward finalize + apply: workgroups per launch (1024; 2048 / 4096 measured slower) */
+ *  39  fused BatchNorm-backward finalize + apply: workgroups per launch (1024; 2048 / 4096 measured slower)
+ *  40  element-wise ablation mask, timing only (0)   41  BN-backward reduce: threads per workgroup (256; 512 / 1024 slower)
+ *  42  BN-backward reduce: fewest pixels per thread (8)
+ *  46  wgrad: 3x3 / stride-2 weight gradients through the LDS-DMA ring kernel (conv_wgrad_dma_s2.hip) (1) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

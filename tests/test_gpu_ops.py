@@ -292,6 +292,47 @@ def test_wgrad_dma_kernel(dt16, M, case, xf):
     assert relerr(res[0], res[1]) < 1e-4            # same products, fp32 accumulation in another order
 
 
+S2_CASES = [  # N, Cin, Cout, H, W  (3x3 / stride 2 / pad 1)
+    (2, 32, 64, 24, 40), (2, 32, 32, 23, 31), (1, 64, 128, 9, 17), (2, 48, 96, 21, 30), (4, 48, 48, 16, 16), (2, 96, 192, 7, 5),
+    (2, 32, 256, 30, 40), (1, 64, 64, 2, 3), (2, 128, 64, 18, 34),
+]
+
+
+@pytest.mark.parametrize("dt16", H16, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("xf", [False, True])
+@pytest.mark.parametrize("case", S2_CASES)
+def test_wgrad_dma_stride2_kernel(dt16, M, case, xf):
+    """conv_wgrad_dma_s2.hip (3x3 / stride 2: the down-sampling convolutions of the fuse layers and transitions, hrnet.py:200-230): odd and even
+    image sizes (the last input row / column is or is not read), images smaller than a sub-tile, channel counts that are multiples of 16
+    but not of 32 (HRNet-W48: blocks that stick out of the tensor), several channel blocks, with and without the producer's fused
+    BatchNorm + ReLU; against autograd on the same rounded operands and against the register-staged kernel it replaces (mfc_set_flag(46, 0))."""
+    _, L, ops = M
+    N, Cin, Cout, H, W = case
+    G = 2 if N % 2 == 0 else 1
+    x = rnd(dt16, N, Cin, H, W, seed=51)
+    xa, coef = x, None
+    if xf:
+        scale, shift = torch.rand(G, Cin) + 0.5, torch.randn(G, Cin) * 0.3
+        coef = torch.zeros(G, 4, Cin)
+        coef[:, 0], coef[:, 1] = scale, shift
+        xa = F.relu(x.view(G, N // G, Cin, H, W) * scale.view(G, 1, Cin, 1, 1) + shift.view(G, 1, Cin, 1, 1)).reshape(N, Cin, H, W)
+        xa = xa.to(dt16).float()
+    w = rnd(dt16, Cout, Cin, 3, 3, seed=52, scale=0.05).requires_grad_(True)
+    y = F.conv2d(xa, w, None, stride=2, padding=1)
+    dy = rnd(dt16, *y.shape, seed=53)
+    y.backward(dy)
+    res = []
+    for flag in (1, 0):
+        L.lib.mfc_set_flag(46, flag)
+        try:
+            res.append(ops.conv2d_wgrad(ops.to_nhwc(x, dt16), ops.to_nhwc(dy, dt16), Cout, Cin, 3, 2,
+                                        in_coef=coef.cuda() if xf else None, in_relu=xf, ipg=N // G).cpu())
+        finally:
+            L.lib.mfc_set_flag(46, 1)
+    assert relerr(res[0], w.grad) < TOL[dt16]
+    assert relerr(res[0], res[1]) < 1e-4            # same products, fp32 accumulation in another order
+
+
 def test_wgrad_fused_input_transform(M):
     _, L, ops = M
     N, Cin, Cout, H, W = 2, 48, 48, 16, 24
