@@ -544,7 +544,9 @@ int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the 
  *  39  fused BatchNorm-backward finalize + apply: workgroups per launch (1024; 2048 / 4096 measured slower)
  *  40  element-wise ablation mask, timing only (0)   41  BN-backward reduce: threads per workgroup (256; 512 / 1024 slower)
  *  42  BN-backward reduce: fewest pixels per thread (8)
- *  46  wgrad: 3x3 / stride-2 weight gradients through the LDS-DMA ring kernel (conv_wgrad_dma_s2.hip) (1) */
+ *  46  wgrad: 3x3 / stride-2 weight gradients through the LDS-DMA ring kernel (conv_wgrad_dma_s2.hip) (1)
+ *  47  wgrad: 3x3 / stride-1 weight gradients with channel counts that are multiples of 48 but not of 32 through the shared-ring kernel
+ *      (conv_wgrad_dma48.hip) (1)                    48  that kernel: twice the workgroups and partial-sum slices per launch (0) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

@@ -42,7 +42,7 @@ int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
-extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma, g_conv_ring, g_ring_ablate, g_ring_wgs, g_conv_stream, g_stream_ablate, g_ring_stagger, g_wgrad_dma_xf8, g_applyfin_blocks, g_ew_ablate, g_bnred_threads, g_bnred_minpx, g_wgrad_dma_s2;
+extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma, g_conv_ring, g_ring_ablate, g_ring_wgs, g_conv_stream, g_stream_ablate, g_ring_stagger, g_wgrad_dma_xf8, g_applyfin_blocks, g_ew_ablate, g_bnred_threads, g_bnred_minpx, g_wgrad_dma_s2, g_wgrad_dma48, g_wgrad_dma48_x2;
 int mfc_stream_set_mt(int v);
 int mfc_ring_set_mt(int v);
 extern "C" int mfc_set_flag(int id, int value) {
@@ -88,6 +88,8 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 41) { g_bnred_threads = value; return 0; }
     if (id == 42) { g_bnred_minpx = value > 0 ? value : 8; return 0; }
     if (id == 46) { g_wgrad_dma_s2 = value; return 0; }
+    if (id == 47) { g_wgrad_dma48 = value; return 0; }
+    if (id == 48) { g_wgrad_dma48_x2 = value; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
@@ -1096,6 +1098,10 @@ static int wgrad_wave(const mfc_wgrad_desc* d, hipStream_t st, int* parts_only, 
 bool wgrad_dma_eligible(const mfc_wgrad_desc* d);
 int wgrad_dma_parts(const mfc_wgrad_desc* d);
 int wgrad_dma_launch(const mfc_wgrad_desc* d, hipStream_t st);
+// conv_wgrad_dma48.hip
+bool wgrad_dma48_eligible(const mfc_wgrad_desc* d);
+int wgrad_dma48_parts(const mfc_wgrad_desc* d);
+int wgrad_dma48_launch(const mfc_wgrad_desc* d, hipStream_t st);
 // conv_wgrad_dma_s2.hip
 bool wgrad_dma_s2_eligible(const mfc_wgrad_desc* d);
 int wgrad_dma_s2_parts(const mfc_wgrad_desc* d);
@@ -1117,6 +1123,10 @@ static int wgrad_any(const mfc_wgrad_desc* d, void* stream, int* parts_only) {
     if (wgrad_dma_eligible(d)) {
         if (parts_only) { *parts_only = wgrad_dma_parts(d); return MFC_OK; }
         return wgrad_dma_launch(d, (hipStream_t)stream);
+    }
+    if (wgrad_dma48_eligible(d)) {
+        if (parts_only) { *parts_only = wgrad_dma48_parts(d); return MFC_OK; }
+        return wgrad_dma48_launch(d, (hipStream_t)stream);
     }
     if (wgrad_dma_s2_eligible(d)) {
         if (parts_only) { *parts_only = wgrad_dma_s2_parts(d); return MFC_OK; }

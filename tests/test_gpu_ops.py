@@ -333,6 +333,44 @@ def test_wgrad_dma_stride2_kernel(dt16, M, case, xf):
     assert relerr(res[0], res[1]) < 1e-4            # same products, fp32 accumulation in another order
 
 
+C48_CASES = [(2, 48, 48, 21, 37), (1, 48, 48, 3, 5), (4, 48, 48, 16, 16), (2, 48, 144, 9, 12), (2, 144, 48, 10, 13), (6, 48, 48, 33, 24)]      # N, Cin, Cout, H, W
+
+
+@pytest.mark.parametrize("dt16", H16, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("xf", [False, True])
+@pytest.mark.parametrize("case", C48_CASES)
+def test_wgrad_dma48_kernel(dt16, M, case, xf):
+    """conv_wgrad_dma48.hip (3x3 / stride 1 with channel counts that are multiples of 48 but not of 32 -- the 48 -> 48 BasicBlocks of HRNet-W48,
+    hrnet.py:297-333): ragged and tiny images, one to three 48 x 48 channel blocks, one to three statistic groups, with and without the
+    producer's fused BatchNorm + ReLU; against autograd on the same rounded operands and against the register-staged kernel it replaces
+    (mfc_set_flag(47, 0))."""
+    _, L, ops = M
+    N, Cin, Cout, H, W = case
+    G = 3 if N % 3 == 0 else (2 if N % 2 == 0 else 1)
+    x = rnd(dt16, N, Cin, H, W, seed=61)
+    xa, coef = x, None
+    if xf:
+        scale, shift = torch.rand(G, Cin) + 0.5, torch.randn(G, Cin) * 0.3
+        coef = torch.zeros(G, 4, Cin)
+        coef[:, 0], coef[:, 1] = scale, shift
+        xa = F.relu(x.view(G, N // G, Cin, H, W) * scale.view(G, 1, Cin, 1, 1) + shift.view(G, 1, Cin, 1, 1)).reshape(N, Cin, H, W)
+        xa = xa.to(dt16).float()
+    w = rnd(dt16, Cout, Cin, 3, 3, seed=62, scale=0.05).requires_grad_(True)
+    y = F.conv2d(xa, w, None, padding=1)
+    dy = rnd(dt16, *y.shape, seed=63)
+    y.backward(dy)
+    res = []
+    for flag in (1, 0):
+        L.lib.mfc_set_flag(47, flag)
+        try:
+            res.append(ops.conv2d_wgrad(ops.to_nhwc(x, dt16), ops.to_nhwc(dy, dt16), Cout, Cin, 3, 1,
+                                        in_coef=coef.cuda() if xf else None, in_relu=xf, ipg=N // G).cpu())
+        finally:
+            L.lib.mfc_set_flag(47, 1)
+    assert relerr(res[0], w.grad) < TOL[dt16]
+    assert relerr(res[0], res[1]) < 1e-4            # same products, fp32 accumulation in another order
+
+
 def test_wgrad_fused_input_transform(M):
     _, L, ops = M
     N, Cin, Cout, H, W = 2, 48, 48, 16, 24
