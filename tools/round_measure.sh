@@ -3,7 +3,7 @@
 #   rocprofv3 kernel stats + PMC passes for W32 and W48, the default bench lines, per-record profiles, what-if runs, the training soak
 set -e
 O=gpurun_out/round; rm -rf $O; mkdir -p $O
-TAG=${1:-r03_d}
+TAG=${1:-r03_e}
 # (the rocprofv3 databases are ~60 MB per width and gpurun returns at most 64 MB: condense them here, keep only the small tables)
 for w in 32 48; do
   bash tools/profile_round.sh $w > $O/profile_round_w$w.log 2>&1
