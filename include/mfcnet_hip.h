@@ -546,7 +546,8 @@ int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the 
  *  42  BN-backward reduce: fewest pixels per thread (8)
  *  46  wgrad: 3x3 / stride-2 weight gradients through the LDS-DMA ring kernel (conv_wgrad_dma_s2.hip) (1)
  *  47  wgrad: 3x3 / stride-1 weight gradients with channel counts that are multiples of 48 but not of 32 through the shared-ring kernel
- *      (conv_wgrad_dma48.hip) (1)                    48  that kernel: twice the workgroups and partial-sum slices per launch (0) */
+ *      (conv_wgrad_dma48.hip) (1)                    48  that kernel: twice the workgroups and partial-sum slices per launch (0)
+ *  50  conv: 48 -> 48 3x3 stride-1 convolutions through conv3x3_ring48.hip (0: correct but slower, see its header)   51  its pixel rows per wave (2; 4) */
 int mfc_set_flag(int id, int value);
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);

@@ -38,12 +38,13 @@ def sign_bits(t_nhwc):
     return (b * w).sum(1).to(torch.uint8).contiguous()
 
 
-def run(L, ops, dtype, shape, variant, ring, mt=4, stream=0):
+def run(L, ops, dtype, shape, variant, ring, mt=4, stream=0, ring48=0):
     N, Cc, H, W, G = shape
     ipg = N // G
     L.lib.mfc_set_flag(30, 1 if ring else 0)
     L.lib.mfc_set_flag(31, mt)
     L.lib.mfc_set_flag(34, stream)
+    L.lib.mfc_set_flag(50, ring48)
     g = torch.Generator().manual_seed(11)
     rd = lambda *s: torch.randn(*s, generator=g).to(dtype).float()
     x = rd(N, Cc, H, W)
@@ -177,3 +178,30 @@ def test_stream_kernel_vs_cpu_and_vs_igemm(M, shape, variant):
     if ref_s is not None:
         assert relerr(s_s[..., :Cc].float(), ref_s) < 5 * TOL[dtype]
         assert relerr(s_s.double(), s_i.double()) < 1e-6
+
+
+C48_SHAPES = [(6, 48, 21, 37, 3), (3, 48, 7, 9, 1), (8, 48, 16, 16, 8), (2, 48, 33, 17, 2), (2, 48, 5, 40, 1), (3, 48, 40, 48, 3)]
+
+
+@pytest.mark.parametrize("variant", ["plain", "stats", "xf+stats", "acc"])
+@pytest.mark.parametrize("shape", C48_SHAPES, ids=lambda s: "N%d_C%d_%dx%d_G%d" % s)
+@pytest.mark.parametrize("dtype", H16, ids=["bf16", "fp16"])
+def test_ring48_kernel_vs_cpu_and_vs_igemm(M, dtype, shape, variant):
+    """conv3x3_ring48_kernel (48 -> 48: the BasicBlocks of HRNet-W48's 120x160 branch, hrnet.py:297-333; k = 32 + k = 16 MFMA steps per tap):
+    ragged shapes, 1-8 statistic groups, statistics / fused input transform / accumulate; against CPU fp32 operators and against
+    conv_igemm (mfc_set_flag(50, 0)), which adds the products up in another order (outputs equal to the storage type's rounding).
+    The kernel is OFF by default (slower than conv_igemm so far); it stays held to these checks."""
+    _, L, ops = M
+    Cc = shape[1]
+    try:
+        o_r, s_r, ref, ref_s, lay_r = run(L, ops, dtype, shape, variant, ring=True, ring48=1)
+        o_i, s_i, _, _, lay_i = run(L, ops, dtype, shape, variant, ring=True, ring48=0)
+    finally:
+        L.lib.mfc_set_flag(50, 0)
+    assert (lay_r.KG, lay_r.nslots, lay_r.NT16, lay_r.nchunks, lay_r.TW) == (6, 54, 48, 1, 16) and lay_r.TH in (8, 16)        # the ring48 layout
+    got = ops.to_nchw(o_r, Cc).cpu()
+    assert relerr(got, ref) < TOL[dtype], (variant, relerr(got, ref))
+    assert relerr(o_r.float(), o_i.float()) < TOL[dtype]
+    if ref_s is not None:
+        assert relerr(s_r[..., :Cc].float(), ref_s) < 5 * TOL[dtype]
+        assert relerr(s_r.double(), s_i.double()) < 1e-4

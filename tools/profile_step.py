@@ -63,7 +63,7 @@ def describe(o, esz):
 
 
 def main():
-    for env, flag in (("MFC_CONV_NW8", 19), ("MFC_WGRAD_DMA48_X2", 48), ("MFC_WGRAD_DMA48", 47), ("MFC_WGRAD_DMA_S2", 46), ("MFC_BNRED_MINPX", 42), ("MFC_BNRED_THREADS", 41), ("MFC_EW_ABLATE", 40), ("MFC_APPLYFIN_BLOCKS", 39), ("MFC_WGRAD_XF8", 38), ("MFC_BNRED_BLOCKS", 27), ("MFC_WGRAD_BLOCKS", 11)):    # tuning switches (include/mfcnet_hip.h)
+    for env, flag in (("MFC_CONV_NW8", 19), ("MFC_WGRAD_DMA48_X2", 48), ("MFC_CONV_RING48", 50), ("MFC_RING48_MT", 51), ("MFC_WGRAD_DMA48", 47), ("MFC_WGRAD_DMA_S2", 46), ("MFC_BNRED_MINPX", 42), ("MFC_BNRED_THREADS", 41), ("MFC_EW_ABLATE", 40), ("MFC_APPLYFIN_BLOCKS", 39), ("MFC_WGRAD_XF8", 38), ("MFC_BNRED_BLOCKS", 27), ("MFC_WGRAD_BLOCKS", 11)):    # tuning switches (include/mfcnet_hip.h)
         if os.environ.get(env):
             L.lib.mfc_set_flag(flag, int(os.environ[env]))
     width = int(sys.argv[1]) if len(sys.argv) > 1 else 32
