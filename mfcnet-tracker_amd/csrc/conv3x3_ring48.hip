@@ -15,11 +15,12 @@
 //     old values requested in front of the MFMA block.
 // Dispatched from mfc_conv2d_fwd / mfc_conv2d_layout when ring48_eligible() (mfc_set_flag(50, 1)).
 //
-// STATUS (round 3): correct (48 parity cases, tests/test_gpu_ring.py) but NOT faster, so OFF by default: 48 -> 48 at 120x160, N = 24: 60.7 us
-// (MT = 2) / 61.7 us (MT = 4) against conv_igemm's 40.3 us.  Ablation (tools/dbg48.py, mfc_set_flag(32, mask)): without the MFMAs 50 us,
-// without MFMAs and DMA 42 us, without MFMAs, DMA and stores 38.5 us -- the per-tap phase structure (two waits for LDS fragments per tap,
-// one wave per SIMD because the 63 / 111 KiB ring + 13.5 KiB of weights allow one workgroup per CU) is latency-bound before any work is done;
-// it needs conv3x3_ring.hip's rolling fragment window and two workgroups per CU (an LDS diet of 640 B) to compete.
+// STATUS (round 3): correct (48 parity cases, tests/test_gpu_ring.py) but NOT faster yet, so OFF by default: 48 -> 48 at 120x160, N = 24:
+// 44-46 us (MT = 2, two workgroups per CU, fragments of tap t + 1 requested under the MFMAs of tap t) against conv_igemm's 40.5 us; the first
+// version (one workgroup per CU, two waits for LDS fragments per tap) took 61 us.  Ablation (tools/dbg48.py, mfc_set_flag(32, mask): 1 / 2 the
+// two MFMA shapes, 4 DMA, 8 stores, 16 fragment reads, 32 epilogue, 64 fix-up): launch + prologue + barriers 8.9 us, fragment reads 8.9,
+// border fix-up 7.2 (30 % of the 8 x 16 tiles are edge tiles and every piece recomputes its pixel coordinates), epilogue 3.1, DMA + stores
+// ~10, MFMAs ~6.  The fix-up and the read block are where the remaining 10-15 us are.
 // One finding worth keeping whatever happens to this kernel: a v_mfma_f32_16x16x16 issued directly behind the v_mfma_f32_16x16x32 that
 // writes its SrcC returned stale rows 0-1 of the accumulator (hipcc 7.2 / gfx950 inserts no wait states between the two shapes); the two
 // phases below keep such pairs 6-12 MFMAs apart.
@@ -321,49 +322,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring48_kernel(Ring48K p) {
         if (has2) issue(tc2, s2);
 
         // ---------------- MFMAs of tile `it`: per tap a k = 32 phase and a k = 16 phase over the wave's MT pixel rows ----------------
-        // Software pipeline across the two phases: the LDS reads of a phase are issued in front of the MFMAs of the phase before it and
-        // land under them (one wave per SIMD: nothing else hides them); sched_barrier keeps hipcc from sinking them next to their use.
-        // The two phases also keep the k = 16 MFMA of an accumulator 12 MFMAs behind the k = 32 one that feeds its SrcC: issued back to
-        // back the pair returned stale rows 0-1 of the accumulator (different pass counts; hipcc 7.2 inserts no wait states on gfx950).
-        {
+        // Software pipeline over the taps: ALL LDS fragments of tap t + 1 (3 weight fragments of the 16-channel remainder, MT + MT pixel
+        // fragments) are requested in front of the 6 MT MFMAs of tap t and land under them; sched_barrier keeps hipcc from sinking them next
+        // to their use.  The two phases also keep the k = 16 MFMA of an accumulator 3 MT MFMAs behind the k = 32 one that feeds its SrcC:
+        // issued back to back the pair returned stale rows 0-1 of the accumulator (different pass counts; hipcc 7.2 inserts no wait states
+        // on gfx950).
+        if (!(p.ablate & 16)) {
             const char* pb = smem + slot * SLOT;
-            bf16x8 b32[MT]; q_s16x4 b16[MT], a16[3];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) b32[mt] = *(const bf16x8*)(pb + adx[0] + mt * ROWA);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+            bf16x8 b32[2][MT]; q_s16x4 b16[2][MT], a16[2][3];
+            auto frags = [&](int tap, int buf) {
                 const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
-                for (int nt = 0; nt < 3; ++nt) a16[nt] = *(const q_s16x4*)(w16l + (tap * 3 + nt) * 512);
+                for (int nt = 0; nt < 3; ++nt) a16[buf][nt] = *(const q_s16x4*)(w16l + (tap * 3 + nt) * 512);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) b16[mt] = *(const q_s16x4*)(pb + bdx[dx] + (mt + dy) * ROWB);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 3; ++nt)
-                        if (!(p.ablate & 2)) acc[mt][nt] = mfma16<T>(wr[tap][nt], b32[mt], acc[mt][nt]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tap < 8) {
-                    const int dy1 = (tap + 1) / 3, dx1 = (tap + 1) - dy1 * 3;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) b32[mt] = *(const bf16x8*)(pb + adx[dx1] + (mt + dy1) * ROWA);
+                for (int mt = 0; mt < MT; ++mt) {
+                    b32[buf][mt] = *(const bf16x8*)(pb + adx[dx] + (mt + dy) * ROWA);
+                    b16[buf][mt] = *(const q_s16x4*)(pb + bdx[dx] + (mt + dy) * ROWB);
                 }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int cur = tap & 1;
+                if (tap < 8) frags(tap + 1, cur ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 3; ++nt)
-                        if (!(p.ablate & 1)) acc[mt][nt] = q_mfma_k16<T>(a16[nt], b16[mt], acc[mt][nt]);
+                        if (!(p.ablate & 2)) acc[mt][nt] = mfma16<T>(wr[tap][nt], b32[cur][mt], acc[mt][nt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt)
+                        if (!(p.ablate & 1)) acc[mt][nt] = q_mfma_k16<T>(a16[cur][nt], b16[cur][mt], acc[mt][nt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         // the patch of the next tile has landed (this wave's pieces; the slot issued above stays in flight), and so have the old values
         if (has1 || ACC) vm_wait(has2 ? npw : 0);
-        if (has1) fixup(tc1, s1);
+        if (has1 && !(p.ablate & 64)) fixup(tc1, s1);
 
         // ---------------- tile epilogue ----------------
-        {
+        if (!(p.ablate & 32)) {
             const int n = tc0.n, i0 = tc0.tyi * TH, j0 = tc0.txi * 16;
             char* tbase = p.out + (((size_t)n * H + i0) * W + j0) * C * 2;
             const bool full = (i0 + TH <= H) && (j0 + 16 <= W);
@@ -462,9 +463,9 @@ static int ring48_setup_t(const mfc_conv_desc* d, Ring48K& k, size_t& lds, int& 
     k.ntiles = d->N * k.tilesY * k.tilesX;
     k.off_w16 = Geo::RING;
     k.off_coef = k.off_w16 + 9 * 3 * 512;
-    k.off_red = k.off_coef + k.G * 2 * Q_C * 4;
-    lds = (size_t)k.off_red + 2 * 384 * 4;
-    grid = 256;                                                  // one workgroup per CU (63 / 111 KiB of ring)
+    k.off_red = k.off_coef + (d->in_coef ? k.G * 2 * Q_C * 4 : 0);
+    lds = (size_t)k.off_red + (d->out_stats ? 2 * 384 * 4 : 0);
+    grid = lds <= 80 * 1024 ? 512 : 256;                         // two workgroups per CU where 63 KiB of ring + weights + tables fit twice
     if (grid > k.ntiles) grid = k.ntiles;
     k.per_block = ceil_div(k.ntiles, grid);
     grid = ceil_div(k.ntiles, k.per_block);

@@ -8,7 +8,7 @@ w = torch.randn(Cc, Cc, 3, 3, device="cuda") * 0.05
 out = torch.zeros(N, H, W, Cc, device="cuda").bfloat16()
 for ring48, mt in ((0, 2), (1, 2)):
     L.lib.mfc_set_flag(50, ring48); L.lib.mfc_set_flag(51, mt)
-    for abl in ((0, 3, 7, 11, 15) if ring48 else (0,)):
+    for abl in ((0, 15, 31, 47, 79, 127) if ring48 else (0,)):
         L.lib.mfc_set_flag(32, abl)
         d = L.ConvDesc(x.data_ptr(), 0, out.data_ptr(), 0, 0, 0, L.BF16, N, H, W, Cc, Cc, H, W, Cc, Cc, H, W, 3, 3, -1, -1, 1, 1, 1, 0, 0, 0, 8, 0, 0, 0)
         wp = ops.pack_weight(w, d, "fwd"); d.wp = wp.data_ptr()
