@@ -55,6 +55,13 @@ __device__ inline void r_dma(const char* base, unsigned voff, unsigned lds) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds) : "memory");
 }
+// the same with a full 64-bit address per lane (border tiles of launches without input transform: out-of-image pixels fetch a zero granule)
+__device__ inline void r_dma64(const char* addr, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(addr), "s"(lds) : "memory");
+}
+__device__ __attribute__((aligned(16))) const unsigned r_zero16[4] = {0u, 0u, 0u, 0u};
 // workgroup barrier that leaves vector-memory operations (the DMA ring, the epilogue's stores) in flight: LDS traffic only
 __device__ inline void r_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -159,7 +166,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
                     else { int py, px, g; piece_src(i, ln, py, px, g); vo = (unsigned)(((py * W + px) * C + g * 8) * 2); }
                     r_dma(pb, vo, lbase + i * 4096);
                 }
-        } else {                        // clamped (always valid) addresses; the out-of-image pixels are zeroed after landing
+        } else if (!p.in_coef) {        // no input transform: out-of-image pixels FETCH zeros (one zero granule, full address per lane) -- no fix-up pass at all
+            const char* zp = (const char*)r_zero16;
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) {
+                if (i < npw) {
+                    int py, px, g;
+                    piece_src(i, ln, py, px, g);
+                    const int iy = i0 - 1 + py, ix = j0 - 1 + px;
+                    const bool inr = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    r_dma64(inr ? img + (size_t)(unsigned)(((iy * W + ix) * C + g * 8) * 2) : zp, lbase + i * 4096);
+                }
+            }
+        } else {                        // clamped (always valid) addresses; the out-of-image pixels are zeroed after landing, behind the transform
 #pragma unroll
             for (int i = 0; i < NPW; ++i) {
                 if (i < npw) {
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
     // (the slot is not read by anybody before the barrier that ends the tile), one barrier per tile whatever the launch fuses.
     auto fixup = [&](const TC& c, int slot) {
         const bool interior = tc_interior(c);
-        if ((!xf && interior) || (p.ablate & 8)) return;
+        if (!xf || (p.ablate & 8)) return;               // (without a transform the border pixels arrived as zeros: issue())
         const int i0 = c.tyi * TH, j0 = c.txi * 16;
         int ln = lane;
         asm volatile("" : "+v"(ln));
