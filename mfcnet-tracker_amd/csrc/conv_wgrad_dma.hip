@@ -161,24 +161,40 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sc[e] = cf[e]; sh[e] = cf[32 + e]; }
         }
+        if constexpr (XF) {
+            // all four granules are READ first and transformed afterwards: as read-modify-write chains one after the other the in-place stores
+            // (which hipcc cannot prove disjoint from the next piece's load) put four LDS round trips in a row in front of every MFMA block
+            uint4 vv[4]; char* aa[4]; bool okk[4], inn[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = xli + 32 * it;                  // (pixel-in-parity-class, granule), granule = idx & 3 = xg
-            const int pc = idx >> 2;
-            if (pc < 30) {
+            for (int it = 0; it < 4; ++it) {
+                const int idx = xli + 32 * it;              // (pixel-in-parity-class, granule), granule = idx & 3 = xg
+                const int pc = min(idx >> 2, 29);
                 const int r3 = pc / WD_PW, px = pc - r3 * WD_PW, py = 2 * r3 + xh;
-                char* a = buf + WD_DBYTES + (py * WD_PW + px) * 64 + xg * 16;
+                aa[it] = buf + WD_DBYTES + (py * WD_PW + px) * 64 + xg * 16;
                 const int iy = i0 - 1 + py, ix = j0 - 1 + px;
-                const bool inr = interior || ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W);
-                if constexpr (XF) {
-                    uint4 v = *(const uint4*)a;
-                    float f[8];
-                    Gran<T>::unpack(v, f);
+                okk[it] = (idx >> 2) < 30;
+                inn[it] = interior || ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W);
+                vv[it] = *(const uint4*)aa[it];
+            }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e] * sc[e] + sh[e], relu_floor);      // (v_max swallows NaN: see conv_wgrad.hip store_tile)
-                    v = Gran<T>::pack(f);
-                    *(uint4*)a = inr ? v : make_uint4(0, 0, 0, 0);
-                } else {
+            for (int it = 0; it < 4; ++it) {
+                float f[8];
+                Gran<T>::unpack(vv[it], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e] * sc[e] + sh[e], relu_floor);      // (v_max swallows NaN: see conv_wgrad.hip store_tile)
+                const uint4 v = Gran<T>::pack(f);
+                if (okk[it]) *(uint4*)aa[it] = inn[it] ? v : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = xli + 32 * it;
+                const int pc = idx >> 2;
+                if (pc < 30) {
+                    const int r3 = pc / WD_PW, px = pc - r3 * WD_PW, py = 2 * r3 + xh;
+                    char* a = buf + WD_DBYTES + (py * WD_PW + px) * 64 + xg * 16;
+                    const int iy = i0 - 1 + py, ix = j0 - 1 + px;
+                    const bool inr = interior || ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W);
                     if (!inr) *(uint4*)a = make_uint4(0, 0, 0, 0);
                 }
             }
