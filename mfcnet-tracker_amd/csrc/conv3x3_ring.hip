@@ -28,6 +28,7 @@ int g_conv_ring = 1;
 int g_ring_ablate = 0;
 int g_ring_stagger = 0;
 int g_ring_wgs = 2;                       // workgroups per CU the grid is sized for (tuning: mfc_set_flag(33, n))
+int g_ring_grid = 0;                      // > 0: workgroups per launch (tuning / probes: mfc_set_flag(52, n)); 0 = 256 * g_ring_wgs
 
 struct RingK {
     const char* in; const char* wp; char* out;
@@ -556,7 +557,7 @@ static void ring_geo(const mfc_conv_desc* d, RingK& k, size_t& lds, int& grid) {
     k.off_bnc = k.off_coef + G * 2 * C * 4;
     k.off_red = k.off_bnc + G * 4 * C * 4;
     lds = (size_t)k.off_red + 2 * 256 * 4;
-    grid = 256 * g_ring_wgs;                                     // two workgroups per CU
+    grid = g_ring_grid > 0 ? g_ring_grid : 256 * g_ring_wgs;     // two workgroups per CU
     if (grid > k.ntiles) grid = k.ntiles;
     k.per_block = ceil_div(k.ntiles, grid);
     grid = ceil_div(k.ntiles, k.per_block);

@@ -42,7 +42,7 @@ int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
-extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma, g_conv_ring, g_ring_ablate, g_ring_wgs, g_conv_stream, g_stream_ablate, g_ring_stagger, g_wgrad_dma_xf8, g_applyfin_blocks, g_ew_ablate, g_bnred_threads, g_bnred_minpx, g_wgrad_dma_s2, g_wgrad_dma48, g_wgrad_dma48_x2, g_conv_ring48, g_ring48_mt;
+extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma, g_conv_ring, g_ring_ablate, g_ring_wgs, g_conv_stream, g_stream_ablate, g_ring_stagger, g_wgrad_dma_xf8, g_applyfin_blocks, g_ew_ablate, g_bnred_threads, g_bnred_minpx, g_wgrad_dma_s2, g_wgrad_dma48, g_wgrad_dma48_x2, g_conv_ring48, g_ring48_mt, g_ring_grid;
 int mfc_stream_set_mt(int v);
 int mfc_ring_set_mt(int v);
 extern "C" int mfc_set_flag(int id, int value) {
@@ -92,6 +92,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 48) { g_wgrad_dma48_x2 = value; return 0; }
     if (id == 50) { g_conv_ring48 = value; return 0; }
     if (id == 51) { g_ring48_mt = (value == 4) ? 4 : 2; return 0; }
+    if (id == 52) { g_ring_grid = value > 0 ? value : 0; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
