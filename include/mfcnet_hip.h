@@ -411,6 +411,9 @@ typedef struct {
     float* dlogits;          /* NCHW fp32 [B, nc, H, W] (bwd) */
     int32_t B, nc, H, W;
     float w_nll, w_jac, grad_scale;
+    int32_t pad_;
+    const float* grad_scale_dev; /* optional (bwd): DEVICE scalar multiplied into the gradient on top of grad_scale -- the upstream gradient autograd hands to
+                                  * the loss node (1, or the loss scale of an fp16 step) without a host read or a separate tensor pass */
 } mfc_loss_desc;
 int mfc_loss_fwd(const mfc_loss_desc* d, void* stream);
 int mfc_loss_partial(const mfc_loss_desc* d, void* stream);

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(mfc_loss_desc d, long tot
     const float eps = 1e-15f;
     const long HW = (long)d.H * d.W;
     const float Wsum = d.acc[1];
+    const float gsc = d.grad_scale * (d.grad_scale_dev ? d.grad_scale_dev[0] : 1.f);
     float aI[8], aU[8];
     for (int c = 0; c < 8; ++c) { aI[c] = 0.f; aU[c] = 0.f; }
     for (int c = 1; c < d.nc; ++c) {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(mfc_loss_desc d, long tot
         for (int c = 0; c < d.nc; ++c) {
             const float gn = wt * (p[c] - (c == t ? 1.f : 0.f));
             const float gj = p[c] * (a[c] - dot);
-            d.dlogits[(b * d.nc + c) * HW + r] = d.grad_scale * (d.w_nll * gn + d.w_jac * gj);
+            d.dlogits[(b * d.nc + c) * HW + r] = gsc * (d.w_nll * gn + d.w_jac * gj);
         }
     }
 }

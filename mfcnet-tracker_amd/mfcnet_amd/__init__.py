@@ -8,8 +8,8 @@ from .model import (HighResolutionNetHIP, HRNetMultiBasic, HRNetMultiLarge, get_
                     get_tooltip_segmentation_model)
 from .resunet import ResUnet_VB  # noqa: F401
 from .optim import FlatAdam  # noqa: F401
-from .loss import mfc_loss  # noqa: F401
+from .loss import get_loss, mfc_loss  # noqa: F401
 from .metrics import confusion_counts, get_metrics  # noqa: F401
 from .checkpoint import load_base_model_weights, load_model_weights, save_model  # noqa: F401
 from .engine import LossScaler, eval_step, train_step  # noqa: F401
-from .dist import DataParallel  # noqa: F401
+from .dist import DataParallel, ShardedStep  # noqa: F401

@@ -131,7 +131,8 @@ class HeadBwd(C.Structure):
 
 class LossDesc(C.Structure):
     _fields_ = [("logits", vp), ("target", vp), ("class_w", vp), ("acc", vp), ("dlogits", vp),
-                ("B", i32), ("nc", i32), ("H", i32), ("W", i32), ("w_nll", f32), ("w_jac", f32), ("grad_scale", f32)]
+                ("B", i32), ("nc", i32), ("H", i32), ("W", i32), ("w_nll", f32), ("w_jac", f32), ("grad_scale", f32), ("pad_", i32),
+                ("grad_scale_dev", vp)]
 
 
 class ProfEntry(C.Structure):

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 
+from ._lib import MfcError
 from .dist import allreduce_grads
 from .loss import DEFAULT_CLASS_WEIGHTS, mfc_loss
 from .metrics import confusion_counts, metrics_from_confusion
@@ -25,12 +26,19 @@ def _forward(model, input, optflow, depth):
     return model(input)
 
 
+def unwrap(model):
+    """the model behind a `mfcnet_amd.DataParallel` / `nn.DataParallel`-style wrapper (`.module`), or the model itself: the flat arenas,
+    the compute dtype, the loss scale and the bucket reducer are attributes of the model, not of its wrapper"""
+    return getattr(model, "module", model)
+
+
 def reduce_gradients(model, world_size, group=None):
     """The data-parallel exchange of a step: finish the per-bucket all-reduces a `dist.GradBucketReducer` started inside the
     backward pass, or -- without one -- reduce the whole arena now.  SUM either way: `mfc_loss(global_batch=True)` already
     normalised the logit gradients over the global batch."""
     if world_size <= 1:
         return
+    model = unwrap(model)
     red = getattr(model, "_bucket_reducer", None)
     if red is not None:
         red.finish()
@@ -48,6 +56,15 @@ class LossScaler:
         self.scale, self.growth_interval, self.check_every = float(init_scale), int(growth_interval), int(check_every)
         self.min_scale, self.max_scale = float(min_scale), float(max_scale)
         self._steps, self._clean, self._seen = 0, 0, 0
+
+    def state_dict(self):
+        return {"scale": self.scale, "growth_interval": self.growth_interval, "check_every": self.check_every, "min_scale": self.min_scale,
+                "max_scale": self.max_scale, "steps": self._steps, "clean": self._clean, "seen": self._seen}
+
+    def load_state_dict(self, sd):
+        self.scale, self.growth_interval, self.check_every = float(sd["scale"]), int(sd["growth_interval"]), int(sd["check_every"])
+        self.min_scale, self.max_scale = float(sd["min_scale"]), float(sd["max_scale"])
+        self._steps, self._clean, self._seen = int(sd["steps"]), int(sd["clean"]), int(sd["seen"])
 
     def update(self, optimizer):
         self._steps += 1
@@ -71,6 +88,7 @@ def loss_scale_for(model, output, world_size=1) -> float:
     out in fp32.  `model.loss_scale` (a number) overrides the rule; `model.loss_scaler` (a LossScaler, created by train_step on first use
     unless `model.loss_scale` pins the scale) adapts it.  B is the GLOBAL batch (world_size x the local one): the loss is normalised over it."""
     from . import _lib as L
+    model = unwrap(model)
     if getattr(model, "compute_dtype", None) != L.F16:
         return 1.0
     s = getattr(model, "loss_scale", None)
@@ -89,20 +107,24 @@ def train_step(model, optimizer, input, mask, optflow=None, depth=None, loss_wts
     """One optimisation step; returns (output logits, acc) with acc[26:29] = (nll, soft_jaccard, total) on the device.
     With world_size > 1 the loss is evaluated over the global batch (26 all-reduced sums) and the ranks' gradients are
     summed, i.e. the arithmetic of the reference's DataParallel step."""
+    core = unwrap(model)              # (a DataParallel wrapper forwards the call; scaler / reducer / arenas belong to the model inside)
+    if world_size > 1 and getattr(core, "base_kind", "hrnet") != "hrnet" and any(p.requires_grad for p in core.base_model.parameters()):
+        raise MfcError("data-parallel training with a trainable external base model (base_model='resunet_vb') is not supported: its parameters "
+                       "live outside the flat arenas, so neither the initial broadcast nor the gradient all-reduce covers them")
     optimizer.zero_grad()
     output = _forward(model, input, optflow, depth)
     loss, acc = mfc_loss(output, mask, class_weights, loss_wts[0], loss_wts[1], global_batch=world_size > 1, group=group)
-    scale = loss_scale_for(model, output, world_size)
-    if scale != 1.0 and getattr(model, "loss_scaler", None) is None and not getattr(model, "loss_scale", None):
-        model.loss_scaler = LossScaler(scale)          # fp16: starts at the static rule's value, then adapts
+    scale = loss_scale_for(core, output, world_size)
+    if scale != 1.0 and getattr(core, "loss_scaler", None) is None and not getattr(core, "loss_scale", None):
+        core.loss_scaler = LossScaler(scale)           # fp16: starts at the static rule's value, then adapts
     (loss if scale == 1.0 else loss * scale).backward()
-    reduce_gradients(model, world_size, group)
+    reduce_gradients(core, world_size, group)
     if scale == 1.0:
         optimizer.step()
     else:
         optimizer.step(grad_scale=1.0 / scale)
-        if getattr(model, "loss_scaler", None) is not None:
-            model.loss_scaler.update(optimizer)
+        if getattr(core, "loss_scaler", None) is not None:
+            core.loss_scaler.update(optimizer)
     return output.detach(), acc
 
 

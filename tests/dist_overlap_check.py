@@ -57,10 +57,33 @@ def main():
     red2.remove()
     rel3 = float((g3 - g2).double().norm() / g2.double().norm())
     ok = ok and torch.equal(g3, g2) and red2.works == []
+    # the same through the nn.DataParallel stand-in: train_step must find the reducer / arenas of the model INSIDE the wrapper
+    from mfcnet_amd.dist import DataParallel, ShardedStep
+    dp = DataParallel(model, device_ids=[0], broadcast=False)
+    mfc.train_step(dp, opt, frames, mask, world_size=2)
+    torch.cuda.synchronize()
+    g4 = model._G.detach().clone()
+    ok_dp = torch.equal(g4, g2) and dp.reducer.works == []
+    dp.reducer.remove()
+    ok = ok and ok_dp
+    # reduce-scatter + sharded FlatAdam + all-gather against all-reduce + replicated FlatAdam: the same parameter bits on every rank
+    p_start = model._P.detach().clone()
+    oa = mfc.FlatAdam(model, lr=1e-3)
+    backward(); allreduce_grads(model, average=False); oa.step()
+    torch.cuda.synchronize()
+    p_a = model._P.detach().clone()
+    model._P.copy_(p_start)
+    ob = mfc.FlatAdam(model, lr=1e-3)
+    sh = ShardedStep(model)
+    backward(); sh.step(ob)
+    torch.cuda.synchronize()
+    p_b = model._P.detach().clone()
+    ok_sh = torch.equal(p_a, p_b) and float((p_a - p_start).abs().max()) > 0
+    ok = ok and ok_sh
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print(f"OVERLAP_CHECK ok={int(flag.item())} rel={rel:.3e} worst_bucket={worst:.3e} loss={l1:.6f}/{l2:.6f} buckets={len(ranges)} train_step_rel={rel3:.3e}", flush=True)
+        print(f"OVERLAP_CHECK ok={int(flag.item())} rel={rel:.3e} worst_bucket={worst:.3e} loss={l1:.6f}/{l2:.6f} buckets={len(ranges)} train_step_rel={rel3:.3e} wrapper={int(ok_dp)} sharded={int(ok_sh)}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if flag.item() == 1.0 else 1)
 

@@ -172,3 +172,48 @@ def test_sixteen_bit_gradient_buckets_and_dataparallel_stand_in():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _sharded_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mfcnet_amd.dist import ShardedStep, allreduce_grads, shard_bounds
+    n = 10_007                                  # not a multiple of world * 4: uneven last shard
+    gen = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=gen)
+    grads = [torch.randn(n, generator=torch.Generator().manual_seed(50 + r)) for r in range(world)]
+
+    def adam_like(P, G, lo, hi):                 # any element-wise update rule: the test is about the exchange
+        P[lo:hi] -= 0.01 * G[lo:hi] / (G[lo:hi].abs().sqrt() + 1e-3)
+
+    # path A: all-reduce (SUM) of the whole arena, replicated update
+    a = SimpleNamespace(_G=grads[rank].clone(), _P=p0.clone())
+    allreduce_grads(a, world, average=False)
+    adam_like(a._P, a._G, 0, n)
+    # path B: reduce-scatter -> update of the own shard -> all-gather
+    b = SimpleNamespace(_G=grads[rank].clone(), _P=p0.clone())
+    sh = ShardedStep(b)
+    sh.step(lambda lo, hi: adam_like(b._P, b._G, lo, hi))
+    bounds = shard_bounds(n, world)
+    ok = bounds[0][0] == 0 and bounds[-1][1] == n and all(lo % 4 == 0 for lo, _ in bounds) and (sh.lo, sh.hi) == bounds[rank]
+    ok = ok and torch.equal(a._P, b._P)          # the same bits on every rank (two ranks: a + b is commutative)
+    ok = ok and torch.equal(a._G[sh.lo:sh.hi], b._G[sh.lo:sh.hi])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_sharded_update_all_gather_equals_allreduce():
+    """dist.ShardedStep (reduce-scatter of the gradient arena, every rank updates its own shard, all-gather of the parameters) against the
+    all-reduce + replicated update, bit for bit, over two gloo ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -433,6 +433,80 @@ def test_engine_steps_match_golden(mfc):
     assert abs(float(acc.cpu()[28]) - float(tot)) < 1e-4
 
 
+def test_reference_step_body_verbatim_with_get_loss(mfc):
+    """The body of the reference's training loop (src/engine.py:54-71) with nothing changed but the imports: zero_grad, the model call, torch's
+    `F.log_softmax`, `get_loss(output, mask, args.loss_fns, args.loss_wts, args)` (src/loss.py:6-21), `math.isnan(loss.item())`, backward,
+    optimizer.step -- against the golden vectors the imported reference produced (loss scalars, post-Adam parameters).  Then the loss terms
+    in the other order / with other weights and a single-term list, against the oracle's terms; an unknown name raises ValueError."""
+    import math
+    from types import SimpleNamespace
+    import torch.nn.functional as F
+    from mfcnet_amd import get_loss
+    cfg, z = load_case("large_rgb_train")
+    model = build(mfc, cfg)
+    set_mode(model, "train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    args = SimpleNamespace(loss_fns=["nll", "soft_jaccard"], loss_wts=[0.7, 0.3], num_classes=5, add_optflow_inputs=False, add_depth_inputs=False,
+                           class_weights=np.array([1.0, 1000.0, 1000.0, 1000.0, 1000.0]))
+    T = cfg["T"]
+    optimizer = torch.optim.Adam([{"params": model.base_model.parameters(), "lr": 1e-4 / T},          # scripts/train_multiframe_detection.py:128-151
+                                  {"params": model.multiframe_net.parameters(), "lr": 1e-4}], lr=1e-4)
+    input = dev(frames)
+    mask = mask.cuda()
+    # ---- src/engine.py:54-71, verbatim
+    optimizer.zero_grad()
+    if args.add_optflow_inputs:
+        output = model(input, optflow=None)
+    elif args.add_depth_inputs:
+        output = model(input, depth=None)
+    else:
+        output = model(input)
+    output = F.log_softmax(output, dim=1)
+    loss, loss_dict = get_loss(output, mask, args.loss_fns, args.loss_wts, args)
+    if math.isnan(loss.item()) or math.isinf(loss.item()):
+        raise AssertionError("loss is not finite")
+    loss.backward()
+    optimizer.step()
+    # ----
+    assert abs(loss_dict["loss_nll"] - float(z["loss_nll"])) < 1e-4 and abs(loss_dict["loss_soft_jaccard"] - float(z["loss_soft_jaccard"])) < 1e-4
+    assert abs(loss_dict["loss_total"] - float(z["loss_total"])) < 1e-4 and set(loss_dict.keys()) == {"loss_nll", "loss_soft_jaccard", "loss_total"}
+    named = dict(model.named_parameters())
+    for key in [f for f in z.files if f.startswith("paramsample/")]:
+        p = key.split("/", 1)[1]
+        lr = 1e-4 / T if p.startswith("base") else 1e-4
+        np.testing.assert_allclose(sample16(named[p]), z[key], rtol=0, atol=2.1 * lr, err_msg=p)
+    # other term lists, on raw logits and on log-probabilities (log_softmax is idempotent), gradient w.r.t. the logits against torch autograd
+    from oracle import mfcnet_oracle as O
+    g = torch.Generator().manual_seed(3)
+    lg = torch.randn(2, 5, 24, 32, generator=g)
+    tg = torch.randint(0, 5, (2, 24, 32), generator=g)
+    _, parts = O.total_loss(lg, tg, 5)
+    for fns, wts in ((["soft_jaccard", "nll"], [0.25, 1.5]), (["nll"], [1.0]), (["soft_jaccard"], [2.0])):
+        want = sum(w * float(parts["loss_" + f]) for f, w in zip(fns, wts))
+        x = lg.clone().cuda().requires_grad_(True)
+        tot, d = get_loss(F.log_softmax(x, dim=1), tg.cuda(), fns, wts, args)
+        tot.backward()
+        xr = lg.clone().requires_grad_(True)
+        lp = F.log_softmax(xr, dim=1)
+        ref = 0.0
+        for f, w in zip(fns, wts):
+            if f == "nll":
+                ref = ref + w * F.nll_loss(lp, tg, weight=torch.tensor(args.class_weights, dtype=torch.float32))
+            else:
+                jl = 0.0
+                for c in range(1, 5):
+                    jt, jo = (tg == c).float(), lp[:, c].exp()
+                    inter = (jo * jt).sum()
+                    jl = jl - torch.log((inter + 1e-15) / (jo.sum() + jt.sum() - inter + 1e-15))
+                ref = ref + w * jl / 5
+        ref.backward()
+        assert abs(float(tot) - want) < 1e-4 * max(1.0, abs(want)) and abs(d["loss_total"] - float(ref)) < 1e-4 * max(1.0, abs(want)), (fns, float(tot), want)
+        assert float((x.grad.cpu() - xr.grad).abs().max()) < 1e-5 * float(xr.grad.abs().max()) + 1e-9, fns
+        assert set(d.keys()) == {"loss_" + f for f in fns} | {"loss_total"}
+    with pytest.raises(ValueError, match="not implemented"):
+        get_loss(lg.cuda(), tg.cuda(), ["wasserstein"], [1.0], args)
+
+
 def test_lanes_do_not_change_results(mfc):
     """The branch lanes / the detached weight-gradient stream (mfc_op.lane) only reorder independent work: a training step
     run with every record on one stream gives the same logits, bit for bit, and the same gradients (weight gradients are partial-sum

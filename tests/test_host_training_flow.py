@@ -148,3 +148,52 @@ def test_train_step_finishes_an_installed_bucket_reducer():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------ round 4
+def test_flat_adam_with_an_external_base_model():
+    """base_model="resunet_vb": the per-frame network's parameters are ordinary nn.Parameters outside the flat arena; FlatAdam used to
+    raise KeyError on the first of them.  It now covers the arena (the temporal head) and steps a torch Adam for the rest."""
+    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, base_model="resunet_vb")
+    opt = mfc.FlatAdam(m, lr=1e-3)
+    assert [g["name"] for g in opt.param_groups] == ["multiframe_net"]
+    ext = [p for n, p in m.named_parameters() if n not in m._poff]
+    assert opt.external is not None and len(opt.external.param_groups[0]["params"]) == len(ext) > 0
+    assert abs(opt.external.param_groups[0]["lr"] - 1e-3 / 3) < 1e-12          # the reference's base-group rate lr / T
+    for p in ext:
+        p.grad = torch.ones_like(p)
+    opt.zero_grad()
+    assert all(p.grad is None for p in ext)
+    sd = opt.state_dict()
+    assert "external" in sd and sd["layout"] == "flat-arena-v1"
+    opt.load_state_dict(sd)
+
+
+def test_flat_adam_state_carries_skip_counter_and_loss_scaler():
+    m = make(frozen=False)
+    m.loss_scaler = mfc.LossScaler(4096.0)
+    m.loss_scaler._steps, m.loss_scaler._clean, m.loss_scaler._seen = 50, 7, 2
+    opt = mfc.FlatAdam(m, lr=1e-3)
+    sd = opt.state_dict()
+    assert sd["skipped_steps"] == 0 and sd["loss_scaler"]["scale"] == 4096.0 and sd["loss_scaler"]["seen"] == 2
+    assert all("_runs" not in g for g in opt.param_groups)          # (the run cache no longer lives in the param_groups)
+    m2 = make(frozen=False)
+    o2 = mfc.FlatAdam(m2, lr=1e-3)
+    sd["skipped_steps"] = 3
+    o2.load_state_dict(sd)
+    assert m2.loss_scaler.scale == 4096.0 and m2.loss_scaler._clean == 7 and o2.skipped_steps() == 3
+
+
+def test_step_helpers_unwrap_the_dataparallel_stand_in():
+    """train_step / reduce_gradients / loss_scale_for read the reducer, the compute dtype and the arenas from the model inside a
+    mfcnet_amd.DataParallel wrapper (they used to look at the wrapper and silently lose the fp16 loss scale)."""
+    from mfcnet_amd import _lib as L
+    from mfcnet_amd.engine import loss_scale_for, unwrap
+    m = make(frozen=False)
+    dp = mfc.DataParallel(m)
+    assert unwrap(dp) is m and unwrap(m) is m
+    m.compute_dtype = L.F16
+    out = torch.empty(8, 5, 480, 640, device="meta")
+    assert loss_scale_for(dp, out) == loss_scale_for(m, out) == 2.0 ** 17
+    opt = mfc.FlatAdam(dp, lr=1e-3)                        # the optimizer accepts the wrapper as well
+    assert opt.model is m
