@@ -25,11 +25,27 @@
  *   - functions return 0 on success, a negative mfc_status otherwise; they never
  *     throw, never allocate device memory, never synchronise (mfc_prof_collect / mfc_prof_dump / mfc_program_profile excepted);
  *     all work is enqueued on `stream` (a hipStream_t; pass torch.cuda.current_stream().cuda_stream);
- *   - the single-operation entry points keep no state between calls.  What IS process-wide: the tuning switches of mfc_set_flag (defaults
- *     are the measured optima; no entry point of the product path changes them) and, per DEVICE, the interpreter's side streams / events
- *     (mfc_program_run creates them on first use).  Consequently programs for one device must be issued from one host thread at a
- *     time (two models may alternate; two threads may not interleave records of the same device).  Per-call behaviour is an argument
- *     (mfc_program_run_ex), not a switch.  The model is not wrappable by nn.DataParallel (one process per GPU instead: INTEGRATION.md).
+ *   - the single-operation entry points keep no state between calls.  Interpreter state (side streams, events) lives in an mfc_ctx handle
+ *     (mfc_ctx_create / mfc_program_run_ctx; one per model in mfcnet_amd); the handle-less mfc_program_run / _ex use a per-device default
+ *     context and are therefore limited to one host thread per device at a time.  Per-call behaviour is an argument (run_flags), not a
+ *     switch.  The only process-wide state left is the tuning switches, which are NOT declared here (mfcnet_hip_tuning.h, tools only) and
+ *     the event profiler's log (mfc_prof_*: a measurement aid).  The model is not wrappable by nn.DataParallel (one process per GPU: INTEGRATION.md).
+ *
+ * SURVEY.md 8(b) lists a minimum set of entry points by working names; the exports that serve them:
+ *   mfc_conv2d_fwd                  -> mfc_conv2d_fwd (k in {1,2,3,11} x any, stride 1/2, bias, fused input transform, fused output statistics)
+ *   mfc_conv2d_dgrad                -> mfc_conv2d_fwd on the data-gradient weight image (mfc_pack_weights mode 1; stride 2 = four parity-class
+ *                                      launches; optional epilogue fusions acc_src / bn_y of mfc_conv_desc)
+ *   mfc_conv2d_wgrad                -> mfc_conv2d_wgrad (+ mfc_conv2d_wgrad_parts / _batch, mfc_unpack_wgrad for the partial-sum slices)
+ *   mfc_bn_finalize                 -> mfc_bn_finalize, mfc_bn_finalize_batch (eval-mode table)
+ *   mfc_bn_bwd_reduce / _apply      -> mfc_bnbwd_reduce, mfc_bnbwd_finalize, mfc_bnbwd_apply (finalize optionally fused into apply)
+ *   mfc_bilinear_up_fwd             -> mfc_combine_fwd (a source whose view is smaller than the output is up-sampled, align_corners=False,
+ *                                      explicit size; sum / BN-apply / ReLU / channel-slice concat in the same pass)
+ *   mfc_bilinear_up_bwd             -> mfc_mask_add (dst smaller than g: adjoint of the up-sampling, optional ReLU mask, accumulate-into)
+ *   mfc_concat_head_gather          -> mfc_head_gather_fwd / mfc_head_gather_bwd (x4 up-sampling + temporal concat + flow / depth, Basic warp)
+ *   mfc_logsoftmax_nll_jaccard_fwd  -> mfc_loss_fwd (= mfc_loss_partial + mfc_loss_finalize; the split form for data-parallel sums)
+ *   mfc_logsoftmax_nll_jaccard_bwd  -> mfc_loss_bwd
+ *   mfc_adam_multi                  -> mfc_adam_step / mfc_adam_step_guarded (one launch per contiguous learning-rate segment of the flat arena)
+ *   *_workspace_bytes()             -> mfc_conv2d_layout (packed-weight bytes, LDS), mfc_conv2d_wgrad_parts (partial-sum slices)
  */
 #ifndef MFCNET_HIP_H
 #define MFCNET_HIP_H
@@ -493,6 +509,15 @@ int mfc_program_run(const mfc_op* ops, int32_t n, void* stream);
  * program of the same step continues on it and the last one joins everything (backward segments of a data-parallel step, see mfc_wait_detached) */
 #define MFC_RUN_DEFER_JOIN 1u
 int mfc_program_run_ex(const mfc_op* ops, int32_t n, void* stream, uint32_t run_flags);
+/* Interpreter state as a HANDLE (round 4; SURVEY.md 8(b) "re-entrant per stream; no hidden globals"): the side streams, fork / join events and
+ * the pending-join state of the detached stream live in an mfc_ctx instead of the per-device default the two calls above use.  One context per
+ * model (mfcnet_amd creates one per module instance): two models never share interpreter state, and two host threads may each drive their
+ * own context -- the calling thread must have the context's device current (MFC_ERR_INVALID_ARG otherwise).  A context is not thread-safe
+ * itself: one thread at a time per context.  Streams / events are created on the first run. */
+int mfc_ctx_create(int32_t device, void** ctx_out);
+int mfc_ctx_destroy(void* ctx);
+int mfc_program_run_ctx(void* ctx, const mfc_op* ops, int32_t n, void* stream, uint32_t run_flags);
+int mfc_wait_detached_ctx(void* ctx, void* stream);      /* mfc_wait_detached for a context's detached stream */
 /* hipGraph form of a program: capture once (the program must have run once before; `stream` must not be the null
  * stream; section lanes / detached records become parallel graph branches), replay with mfc_graph_launch.  All pointers in
  * the records are baked into the graph, which is what the static plan guarantees.  Measured on MI355X / ROCm 7.2: no faster
@@ -518,40 +543,8 @@ int mfc_prof_enable(int on);
 int mfc_prof_dump(const char* csv_path);                     /* tuning aid: the recorded launches as a timeline (name, stream, start_us, end_us); clears the log */
 int mfc_prof_collect(mfc_prof_entry* out, int32_t cap);     /* synchronises the recorded events, fills out[0..n), clears the log; returns n (< 0: error) */
 
-/* Tuning switches (defaults are the measured optima; the tools/ scripts sweep them).  Process-global, not thread-safe.
- *   1  wgrad: use ds_read_b64_tr_b16 (1)            2  conv: force pixel-tile MT (0 = search)     3  wgrad: K-split mode (0)
- *   4  conv: persistent workgroups per launch (512)  5  conv: ablation mask (0)                    6  conv: LDS budget KiB (80)
- *   7  wgrad: ablation mask (0)                      8  conv: cout-block-fastest unit order (-1 auto)
- *   9  lanes: bit 0 parallel-section lanes, bit 1 detached records (3); 0 = every record on the caller's stream
- *  10  detached streams in use (1)                  11  wgrad: target workgroups per launch (256; sizes the partial-sum slices)
- *  12  lane -> stream folding (n streams, or a 4-digit map such as 1221)   13  run detached records on side lane k (0 = own stream)
- *  14  program main stream = interpreter's own (0)  15  what-if: skip record kinds (bit mask, timing only)
- *  16  detached stream priority (0; read at stream creation)              17  wgrad: prefetch-distance-2 variant (0)
- *  18  conv: exponent (%) of the under-filled-launch penalty (100)         19  conv: score weight (%) of the 8-wave geometries (90)
- *  20  conv: single-stage launches keep every cout block's weights in LDS and stage each pixel tile once (1)
- *  21  wgrad: output pixels per workgroup above which the pixel axis is split further than switch 11 asks (6000; 0 = never)
- *  22  lanes: measure which side streams really overlap with the caller's stream before choosing them (1; see runtime.hip)
- *  23  conv: big 1x1 / stride-1 convolutions without input transform run as a plain GEMM (conv_gemm1x1.hip) (1)
- *  24  conv: smallest Cin and Cout sent to that GEMM (128)
- *  25  wgrad: 1x1 weight gradients without input transform as a split-K GEMM (wgrad_gemm1x1.hip) (1)
- *  26  wgrad: smallest Cin and Cout sent to that GEMM (64)           27  BN-backward reduce: workgroups per launch (1024; 512-2048 measured equal)
- *  28  program: defer the final join of the detached stream to the next program (0; tuning only -- the product path passes
- *      MFC_RUN_DEFER_JOIN to mfc_program_run_ex instead)
- *  29  wgrad: 3x3 / stride-1 weight gradients of 32-channel-multiple layers through the LDS-DMA ring kernel (conv_wgrad_dma.hip) (1)
- *  30  conv: 32 -> 32 / 64 -> 64 3x3 stride-1 convolutions through the register-resident-weight ring kernel (conv3x3_ring.hip) (1)
- *  31  ring kernel: 16-pixel rows per wave (4; 2)    32  ring kernel: ablation mask (0)             33  ring kernel: workgroups per CU (2)
- *  34  conv: 128 / 256-channel 3x3 through the two-ring stream kernel (conv3x3_stream.hip) (0: correct but slower, see its header)
- *  35  stream kernel: ablation mask (0)              36  stream kernel: force form 10 * MSH + MT (0)
- *  37  ring kernel: start delay of the workgroup in the odd wave slot of a CU (0; no effect measured)
- *  38  wgrad DMA kernel: 8 waves per workgroup for launches with an input transform (0: faster alone, slower in the step)
- *  39  fused BatchNorm-backward finalize + apply: workgroups per launch (1024; 2048 / 4096 measured slower)
- *  40  element-wise ablation mask, timing only (0)   41  BN-backward reduce: threads per workgroup (256; 512 / 1024 slower)
- *  42  BN-backward reduce: fewest pixels per thread (8)
- *  46  wgrad: 3x3 / stride-2 weight gradients through the LDS-DMA ring kernel (conv_wgrad_dma_s2.hip) (1)
- *  47  wgrad: 3x3 / stride-1 weight gradients with channel counts that are multiples of 48 but not of 32 through the shared-ring kernel
- *      (conv_wgrad_dma48.hip) (1)                    48  that kernel: twice the workgroups and partial-sum slices per launch (0)
- *  50  conv: 48 -> 48 3x3 stride-1 convolutions through conv3x3_ring48.hip (0: correct but slower, see its header)   51  its pixel rows per wave (2; 4) */
-int mfc_set_flag(int id, int value);
+/* The tuning switches (mfc_set_flag and its table) are NOT part of this interface: they are declared in mfcnet_hip_tuning.h, which only the
+ * measurement scripts under tools/ and the tests include.  No entry point of the product path changes a switch. */
 int mfc_op_size(void);      /* sizeof(mfc_op), so the host side can check its mirror */
 const char* mfc_version(void);
 

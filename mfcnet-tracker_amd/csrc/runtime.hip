@@ -291,6 +291,7 @@ static int adam_step_impl(float* p, const float* g, float* m, float* v, int64_t 
 // Rows are keyed by kernel NAME (the string rocprofv3 prints for that kernel, demangled), so bench.py's `roofline` object and the
 // committed rocprofv3 kernel-stats table talk about the same rows.
 #include <vector>
+#include <new>
 #include <string.h>
 int g_mfc_prof_on = 0;
 namespace {
@@ -503,10 +504,17 @@ static bool streams_overlap(hipStream_t a, hipStream_t b) {
     return over;
 }
 
+// Interpreter state = one LaneSet.  The classic entry points (mfc_program_run / _ex, mfc_wait_detached, mfc_graph_capture) use the
+// per-DEVICE default set g_lanes[dev]; mfc_ctx_create makes a set of its own that mfc_program_run_ctx / mfc_wait_detached_ctx take as an
+// argument, so that two models (or two host threads, each with its device current) never share streams, events or the pending-join state.
+struct mfc_ctx_s { int device; LaneSet L; };
+static LaneSet* lanes_get(LaneSet* L, hipStream_t caller, bool may_probe);
 static LaneSet* lanes_for_device(hipStream_t caller = nullptr, bool may_probe = false) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    LaneSet* L = &g_lanes[dev];
+    return lanes_get(&g_lanes[dev], caller, may_probe);
+}
+static LaneSet* lanes_get(LaneSet* L, hipStream_t caller, bool may_probe) {
     if (!L->ready) {
         if (hipStreamCreateWithFlags(&L->m, hipStreamNonBlocking) != hipSuccess) return nullptr;
         for (int i = 2; i <= 3; ++i)
@@ -577,21 +585,70 @@ static bool g_capturing = false;      // (a captured program stays on the captur
 // MFC_OP_UNPACK / the program end -- the weight gradients.  Such a record waits (event) for everything issued so far on
 // the stream it would have run on, then runs on an extra stream, so the MFMA-bound wgrad launches overlap the HBM-bound
 // BatchNorm-backward sweeps and the data-gradient chain instead of sitting in it.
-static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_join);
+static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_join, LaneSet* own = nullptr);
 extern "C" int mfc_program_run(const mfc_op* ops, int32_t n, void* stream) { return program_run(ops, n, stream, g_defer_join != 0); }
 // the same with per-call options instead of process-wide switches: MFC_RUN_DEFER_JOIN = do not join the detached stream at the end (the
 // next program of the step continues on it; see mfc_wait_detached)
 extern "C" int mfc_program_run_ex(const mfc_op* ops, int32_t n, void* stream, uint32_t run_flags) {
     return program_run(ops, n, stream, (run_flags & MFC_RUN_DEFER_JOIN) != 0);
 }
-static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_join) {
+// ---- context handles: interpreter state as an argument instead of a per-device global (include/mfcnet_hip.h) ----
+extern "C" int mfc_ctx_create(int32_t device, void** ctx_out) {
+    if (!ctx_out || device < 0) return MFC_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
+    if (ndev > 0 && device >= ndev) return MFC_ERR_INVALID_ARG;
+    mfc_ctx_s* c = new (std::nothrow) mfc_ctx_s();
+    if (!c) return MFC_ERR_LAUNCH;
+    c->device = device;
+    memset(&c->L, 0, sizeof(c->L));           // streams / events are made on first use, by the thread that has `device` current
+    *ctx_out = (void*)c;
+    return MFC_OK;
+}
+extern "C" int mfc_ctx_destroy(void* ctx) {
+    mfc_ctx_s* c = (mfc_ctx_s*)ctx;
+    if (!c) return MFC_ERR_INVALID_ARG;
+    LaneSet& L = c->L;
+    if (L.ready) {
+        (void)hipStreamDestroy(L.m);
+        for (int i = 2; i <= MFC_MAX_LANES; ++i) (void)hipStreamDestroy(L.s[i]);
+        for (int i = 0; i < MFC_ASYNC_STREAMS; ++i) { (void)hipStreamDestroy(L.as[i]); (void)hipEventDestroy(L.ajoin[i]); }
+        (void)hipEventDestroy(L.enter); (void)hipEventDestroy(L.leave); (void)hipEventDestroy(L.fork); (void)hipEventDestroy(L.seg);
+        for (int i = 2; i <= MFC_MAX_LANES; ++i) (void)hipEventDestroy(L.join[i]);
+        for (int i = 0; i < MFC_ASYNC_EVENTS; ++i) (void)hipEventDestroy(L.aev[i]);
+        (void)hipGetLastError();
+    }
+    delete c;
+    return MFC_OK;
+}
+static int ctx_check(mfc_ctx_s* c) {
+    if (!c) return MFC_ERR_INVALID_ARG;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return MFC_ERR_LAUNCH;
+    return dev == c->device ? MFC_OK : MFC_ERR_INVALID_ARG;      // the calling thread must have the context's device current
+}
+extern "C" int mfc_program_run_ctx(void* ctx, const mfc_op* ops, int32_t n, void* stream, uint32_t run_flags) {
+    mfc_ctx_s* c = (mfc_ctx_s*)ctx;
+    const int rc = ctx_check(c);
+    if (rc != MFC_OK) return rc;
+    return program_run(ops, n, stream, (run_flags & MFC_RUN_DEFER_JOIN) != 0, &c->L);
+}
+extern "C" int mfc_wait_detached_ctx(void* ctx, void* stream) {
+    mfc_ctx_s* c = (mfc_ctx_s*)ctx;
+    const int rc = ctx_check(c);
+    if (rc != MFC_OK) return rc;
+    if (!c->L.ready || !c->L.pending) return MFC_OK;
+    return hipStreamWaitEvent((hipStream_t)stream, c->L.seg, 0) == hipSuccess ? MFC_OK : MFC_ERR_LAUNCH;
+}
+
+static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_join, LaneSet* own) {
     if (!ops || n < 0) return MFC_ERR_INVALID_ARG;
     hipStream_t caller = (hipStream_t)stream;
     LaneSet* L = nullptr;
     bool multi = false;
     if (g_lanes_on)
         for (int i = 0; i < n && !multi; ++i) multi = ops[i].lane != 0;
-    if (multi && !(L = lanes_for_device(caller, !g_capturing))) return MFC_ERR_LAUNCH;
+    if (multi && !(L = (own ? lanes_get(own, caller, !g_capturing) : lanes_for_device(caller, !g_capturing)))) return MFC_ERR_LAUNCH;
     // with lanes the whole program runs on the interpreter's own streams, ordered after / before the caller's stream by events
     hipStream_t mainst = (multi && !g_capturing && g_own_main) ? L->m : caller;
     if (mainst != caller) { (void)hipEventRecord(L->enter, caller); (void)hipStreamWaitEvent(mainst, L->enter, 0); }

@@ -158,7 +158,10 @@ EXPORTS = ["mfc_conv2d_fwd", "mfc_conv2d_layout", "mfc_conv2d_lds_bytes", "mfc_p
            "mfc_bn_finalize", "mfc_bn_finalize_batch", "mfc_ws_normalize", "mfc_gn_finalize", "mfc_upsample_nearest2x", "mfc_gnbwd_finalize", "mfc_ws_backward", "mfc_upsample_nearest2x_bwd", "mfc_combine_fwd", "mfc_bnbwd_reduce", "mfc_bnbwd_apply", "mfc_bnbwd_finalize",
            "mfc_mask_add", "mfc_bias_grad", "mfc_bias_grad_slices", "mfc_nchw_to_nhwc", "mfc_nhwc_to_nchw", "mfc_head_gather_fwd",
            "mfc_head_gather_bwd", "mfc_loss_fwd", "mfc_loss_partial", "mfc_loss_finalize", "mfc_loss_bwd", "mfc_confusion_counts", "mfc_adam_step", "mfc_adam_step_guarded", "mfc_grad_check", "mfc_program_run", "mfc_program_run_ex", "mfc_wait_detached", "mfc_program_profile", "mfc_graph_capture", "mfc_graph_launch", "mfc_graph_destroy",
-           "mfc_set_flag", "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect", "mfc_prof_dump"]
+           "mfc_ctx_create", "mfc_ctx_destroy", "mfc_program_run_ctx", "mfc_wait_detached_ctx",
+           "mfc_op_size", "mfc_version", "mfc_prof_enable", "mfc_prof_collect", "mfc_prof_dump"]
+# include/mfcnet_hip_tuning.h (tools / A-B measurements only: not part of the product interface)
+TUNING_EXPORTS = ["mfc_set_flag"]
 
 
 class MfcError(RuntimeError):
@@ -170,11 +173,11 @@ def _load():
         raise MfcError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
                        f"`make -C mfcnet-tracker_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback path.")
     lib = C.CDLL(LIB_PATH)
-    for name in EXPORTS:
+    for name in EXPORTS + TUNING_EXPORTS:
         if not hasattr(lib, name):
             raise MfcError(f"{LIB_PATH} does not export {name}")
     lib.mfc_version.restype = C.c_char_p
-    for name in EXPORTS:
+    for name in EXPORTS + TUNING_EXPORTS:
         if name not in ("mfc_version",):
             getattr(lib, name).restype = C.c_int
     lib.mfc_program_run.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -182,6 +185,10 @@ def _load():
     lib.mfc_program_profile.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mfc_graph_capture.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mfc_wait_detached.argtypes = [C.c_void_p]
+    lib.mfc_ctx_create.argtypes = [C.c_int32, C.c_void_p]
+    lib.mfc_ctx_destroy.argtypes = [C.c_void_p]
+    lib.mfc_program_run_ctx.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32]
+    lib.mfc_wait_detached_ctx.argtypes = [C.c_void_p, C.c_void_p]
     lib.mfc_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
     lib.mfc_graph_destroy.argtypes = [C.c_void_p]
     lib.mfc_bias_grad.argtypes = [vp, vp, i32, C.c_int64, i32, i32, vp]
@@ -217,6 +224,31 @@ def _load():
 
 
 lib = _load()
+
+
+class Ctx:
+    """An interpreter context (mfc_ctx_create): the side streams / events a model's programs run on.  One per model; destroyed with it."""
+
+    def __init__(self, device_index: int):
+        self.handle = C.c_void_p()
+        check_rc = lib.mfc_ctx_create(int(device_index), C.byref(self.handle))
+        if check_rc != 0:
+            raise MfcError(f"mfc_ctx_create(device {device_index}) failed with status {check_rc}")
+        self.device_index = int(device_index)
+
+    def __deepcopy__(self, memo):          # a copied model gets a context of its own (handles are never shared)
+        return Ctx(self.device_index)
+
+    def __reduce__(self):
+        return (Ctx, (self.device_index,))
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                lib.mfc_ctx_destroy(h)
+            except Exception:
+                pass
 
 
 def check(rc: int, what: str = "mfc call"):

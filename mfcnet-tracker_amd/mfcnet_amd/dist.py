@@ -208,7 +208,11 @@ class GradBucketReducer:
             if self._comm is None:
                 self._comm = torch.cuda.Stream()
             self._comm.wait_stream(torch.cuda.current_stream())
-            L.check(L.lib.mfc_wait_detached(C.c_void_p(self._comm.cuda_stream)), "mfc_wait_detached")
+            ctx = getattr(self.model, "_ctx", None)          # the model's interpreter context (its detached stream)
+            if ctx is not None:
+                L.check(L.lib.mfc_wait_detached_ctx(ctx.handle, C.c_void_p(self._comm.cuda_stream)), "mfc_wait_detached_ctx")
+            else:
+                L.check(L.lib.mfc_wait_detached(C.c_void_p(self._comm.cuda_stream)), "mfc_wait_detached")
             with torch.cuda.stream(self._comm):
                 if self.wire_dtype is not None:
                     wire = sl.to(self.wire_dtype)

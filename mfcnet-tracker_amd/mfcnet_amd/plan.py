@@ -970,6 +970,14 @@ class Plan:
         o = off - a.buf.data_ptr()
         return a.buf[o:o + 4 * n].view(torch.float32).view(shape)
 
+    def _run(self, prog, flags):
+        """one host call per program, on the model's own interpreter context (mfc_ctx: its side streams / events are not shared with any other
+        model or thread, include/mfcnet_hip.h)"""
+        ctx = getattr(self.m, "_ctx", None)
+        if ctx is None or ctx.device_index != self.device.index:
+            ctx = self.m._ctx = L.Ctx(self.device.index if self.device.index is not None else torch.cuda.current_device())
+        return L.lib.mfc_program_run_ctx(ctx.handle, prog, len(prog), L.stream_ptr(), flags)
+
     def run_forward(self, frames, flow, depth, ext_logits=None):
         B, T, H, W = self.B, self.T, self.H, self.W
         if self.ext_base:
@@ -981,7 +989,7 @@ class Plan:
             self._io(p, (B, 2, H, W)).copy_(flow[i])
         for i, p in enumerate(self.in_depth):
             self._io(p, (B, 1, H, W)).copy_(depth[i])
-        rc = L.lib.mfc_program_run(self.fwd_prog, len(self.fwd_prog), L.stream_ptr())
+        rc = self._run(self.fwd_prog, 0)
         if rc != 0:
             raise L.MfcError(f"forward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
         return self._io(self.out_buf, (B, self.nc, H, W)).clone()
@@ -990,7 +998,7 @@ class Plan:
         self._io(self.gout_buf, (self.B, self.nc, self.H, self.W)).copy_(grad_out)
         hook = getattr(self.m, "grad_bucket_hook", None)
         if hook is None:
-            rc = L.lib.mfc_program_run(self.bwd_prog, len(self.bwd_prog), L.stream_ptr())
+            rc = self._run(self.bwd_prog, 0)
             if rc != 0:
                 raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
             return self._ext_grad()
@@ -999,7 +1007,7 @@ class Plan:
             # every segment but the last leaves the detached stream un-joined (the chain does not wait for the weight gradients of the
             # segment); the bucket's consumer orders itself after them with mfc_wait_detached
             defer = self.lanes and i + 1 < nseg
-            rc = L.lib.mfc_program_run_ex(prog, len(prog), L.stream_ptr(), L.RUN_DEFER_JOIN if defer else 0)
+            rc = self._run(prog, L.RUN_DEFER_JOIN if defer else 0)
             if rc != 0:
                 raise L.MfcError(f"backward program failed: record {(-rc) // 1000 - 1 if rc <= -1000 else '?'} status {rc}")
             if hook is not None:

@@ -22,8 +22,11 @@ def L():
     return _lib
 
 
-def declared_functions():
-    src = open(HEADER).read()
+TUNING_HEADER = os.path.join(ROOT, "include", "mfcnet_hip_tuning.h")
+
+
+def declared_functions(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(mfc_[a-z0-9_]+)\s*\(", src)))
 
@@ -36,6 +39,15 @@ def test_library_exports_every_declared_symbol(L):
     assert not missing, missing
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
     assert b"gfx950" in L.lib.mfc_version()
+    # the tuning switches are a separate, private header: exported for tools/, absent from the product interface
+    tuning = declared_functions(TUNING_HEADER)
+    assert tuning == sorted(L.TUNING_EXPORTS) == ["mfc_set_flag"] and not (set(tuning) & set(names))
+    assert all(hasattr(lib, n) for n in tuning)
+    # the context API: handles are created without touching a device, validated, destroyed
+    h = C.c_void_p()
+    assert L.lib.mfc_ctx_create(0, C.byref(h)) == 0 and h.value
+    assert L.lib.mfc_ctx_destroy(h) == 0
+    assert L.lib.mfc_ctx_create(-1, C.byref(h)) == -1 and L.lib.mfc_ctx_destroy(None) == -1
 
 
 def test_ctypes_mirrors_match_c_struct_sizes(L):
