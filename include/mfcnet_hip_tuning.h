@@ -30,8 +30,7 @@ extern "C" {
  *  29  wgrad: 3x3 / stride-1 weight gradients of 32-channel-multiple layers through the LDS-DMA ring kernel (conv_wgrad_dma.hip) (1)
  *  30  conv: 32 -> 32 / 64 -> 64 3x3 stride-1 convolutions through the register-resident-weight ring kernel (conv3x3_ring.hip) (1)
  *  31  ring kernel: 16-pixel rows per wave (4; 2)    32  ring kernel: ablation mask (0)             33  ring kernel: workgroups per CU (2)
- *  34  conv: 128 / 256-channel 3x3 through the two-ring stream kernel (conv3x3_stream.hip) (0: correct but slower, see its header)
- *  35  stream kernel: ablation mask (0)              36  stream kernel: force form 10 * MSH + MT (0)
+ *  34-36  (round 3's conv3x3_stream.hip: removed in round 4 -- measured slower)
  *  37  ring kernel: start delay of the workgroup in the odd wave slot of a CU (0; no effect measured)
  *  38  wgrad DMA kernel: 8 waves per workgroup for launches with an input transform (0: faster alone, slower in the step)
  *  39  fused BatchNorm-backward finalize + apply: workgroups per launch (1024; 2048 / 4096 measured slower)
@@ -40,7 +39,10 @@ extern "C" {
  *  46  wgrad: 3x3 / stride-2 weight gradients through the LDS-DMA ring kernel (conv_wgrad_dma_s2.hip) (1)
  *  47  wgrad: 3x3 / stride-1 weight gradients with channel counts that are multiples of 48 but not of 32 through the shared-ring kernel
  *      (conv_wgrad_dma48.hip) (1)                    48  that kernel: twice the workgroups and partial-sum slices per launch (0)
- *  50  conv: 48 -> 48 3x3 stride-1 convolutions through conv3x3_ring48.hip (0: correct but slower, see its header)   51  its pixel rows per wave (2; 4) */
+ *  50-51  (round 3's conv3x3_ring48.hip: removed in round 4 -- measured slower)
+ *  52  ring kernel: workgroups per launch (0 = 256 x switch 33; probes of partitioned grids, tools/probe_group.py)
+ *  53  descriptor hardening (0): 1 = every non-null pointer of a convolution / weight-gradient / combine / BatchNorm-backward / mask-add descriptor is checked with
+ *      hipPointerGetAttributes before the launch (MFC_ERR_INVALID_ARG for host or unmapped addresses instead of a GPU fault); the -m gpu tests run with it on */
 int mfc_set_flag(int id, int value);
 #ifdef __cplusplus
 }

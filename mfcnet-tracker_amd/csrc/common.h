@@ -164,6 +164,17 @@ static inline bool mfc_dtype_ok(int dtype) { return dtype == MFC_F32 || mfc_is16
     if ((dtype) == MFC_F16) { typedef f16_t T; __VA_ARGS__; } else { typedef bf16_t T; __VA_ARGS__; } } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// Optional descriptor hardening (mfc_set_flag(53, 1); the -m gpu test session switches it on): every non-null pointer of a descriptor must
+// be DEVICE memory known to the HIP runtime (hipPointerGetAttributes), otherwise the entry point returns MFC_ERR_INVALID_ARG instead of
+// launching a kernel that would fault the GPU.  Round 3 lost two test runs to exactly that: descriptors cloned from a dry plan (placeholder
+// addresses) reached mfc_conv2d_fwd / mfc_combine_fwd with the placeholder of the folded BatchNorm finalize still in `in_fin` / `fin`.
+extern int g_mfc_validate_ptrs;
+bool mfc_ptrs_ok_impl(const void* const* p, int n);
+template <typename... P> static inline bool mfc_ptrs_ok(P... ptrs) {
+    if (!g_mfc_validate_ptrs) return true;
+    const void* a[] = {(const void*)(uintptr_t)ptrs...};
+    return mfc_ptrs_ok_impl(a, (int)(sizeof(a) / sizeof(a[0])));
+}
 #define MFC_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return MFC_ERR_LAUNCH; } while (0)
 
 // ---- BatchNorm finalize folded into a consumer launch (mfc_conv_desc.in_fin / mfc_combine_desc.fin): called by ALL threads of EVERY workgroup

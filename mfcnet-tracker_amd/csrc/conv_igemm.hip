@@ -845,14 +845,6 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
 bool ring_eligible(const mfc_conv_desc* d);
 int ring_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
 int ring_launch(const mfc_conv_desc* d, hipStream_t st);
-// conv3x3_ring48.hip
-bool ring48_eligible(const mfc_conv_desc* d);
-int ring48_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
-int ring48_launch(const mfc_conv_desc* d, hipStream_t st);
-// conv3x3_stream.hip
-bool stream_eligible(const mfc_conv_desc* d);
-int stream_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
-int stream_launch(const mfc_conv_desc* d, hipStream_t st);
 // conv_gemm1x1.hip
 bool gemm1x1_eligible(const mfc_conv_desc* d);
 int gemm1x1_layout(const mfc_conv_desc* d, mfc_conv_layout* out);
@@ -861,8 +853,6 @@ int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st);
 extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
     if (!d) return MFC_ERR_INVALID_ARG;
     if (out && ring_eligible(d)) return ring_layout(d, out);
-    if (out && ring48_eligible(d)) return ring48_layout(d, out);
-    if (out && stream_eligible(d)) return stream_layout(d, out);
     if (out && gemm1x1_eligible(d)) return gemm1x1_layout(d, out);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     mfc_conv_desc t = *d;
@@ -882,8 +872,6 @@ extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
 extern "C" int mfc_conv2d_lds_bytes(const mfc_conv_desc* d) {
     if (!d) return MFC_ERR_INVALID_ARG;
     if (ring_eligible(d)) { mfc_conv_layout l; const int rc = ring_layout(d, &l); return rc < 0 ? rc : l.lds_bytes; }
-    if (ring48_eligible(d)) { mfc_conv_layout l; const int rc = ring48_layout(d, &l); return rc < 0 ? rc : l.lds_bytes; }
-    if (stream_eligible(d)) { mfc_conv_layout l; const int rc = stream_layout(d, &l); return rc < 0 ? rc : l.lds_bytes; }
     if (gemm1x1_eligible(d)) { mfc_conv_layout l; gemm1x1_layout(d, &l); return l.lds_bytes; }
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
@@ -945,9 +933,8 @@ static int conv_dispatch(const ConvK& k, int MT, int PM, int NW, size_t lds, int
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
     if (!d) return MFC_ERR_INVALID_ARG;
     if (d->in_fin && !d->in_coef) return MFC_ERR_INVALID_ARG;        // a folded finalize writes the block this launch reads as in_coef
+    if (!mfc_ptrs_ok(d->in, d->wp, d->out, d->bias, d->in_coef, d->out_stats, d->acc_src, d->bn_y, d->bn_coef, d->bn_bits, d->in_fin)) return MFC_ERR_INVALID_ARG;
     if (ring_eligible(d)) return ring_launch(d, (hipStream_t)stream);
-    if (ring48_eligible(d)) return ring48_launch(d, (hipStream_t)stream);
-    if (stream_eligible(d)) return stream_launch(d, (hipStream_t)stream);
     const bool fused = d && (d->acc_src || d->bn_y);
     if (d && gemm1x1_eligible(d)) return fused ? MFC_ERR_UNSUPPORTED : gemm1x1_launch(d, (hipStream_t)stream);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;

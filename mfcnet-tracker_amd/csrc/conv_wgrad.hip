@@ -42,8 +42,7 @@ int mfc_set_skip_kinds(int m);
 int mfc_set_async_prio(int v);
 int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
-extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma, g_conv_ring, g_ring_ablate, g_ring_wgs, g_conv_stream, g_stream_ablate, g_ring_stagger, g_wgrad_dma_xf8, g_applyfin_blocks, g_ew_ablate, g_bnred_threads, g_bnred_minpx, g_wgrad_dma_s2, g_wgrad_dma48, g_wgrad_dma48_x2, g_conv_ring48, g_ring48_mt, g_ring_grid;
-int mfc_stream_set_mt(int v);
+extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma, g_conv_ring, g_ring_ablate, g_ring_wgs, g_ring_stagger, g_wgrad_dma_xf8, g_applyfin_blocks, g_ew_ablate, g_bnred_threads, g_bnred_minpx, g_wgrad_dma_s2, g_wgrad_dma48, g_wgrad_dma48_x2, g_ring_grid;
 int mfc_ring_set_mt(int v);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
@@ -78,9 +77,6 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 31) return mfc_ring_set_mt(value);
     if (id == 32) { g_ring_ablate = value; return 0; }
     if (id == 33) { g_ring_wgs = value > 0 ? value : 2; return 0; }
-    if (id == 34) { g_conv_stream = value; return 0; }
-    if (id == 35) { g_stream_ablate = value; return 0; }
-    if (id == 36) return mfc_stream_set_mt(value);
     if (id == 37) { g_ring_stagger = value; return 0; }
     if (id == 38) { g_wgrad_dma_xf8 = value; return 0; }
     if (id == 39) { g_applyfin_blocks = value > 0 ? value : 1024; return 0; }
@@ -90,9 +86,8 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 46) { g_wgrad_dma_s2 = value; return 0; }
     if (id == 47) { g_wgrad_dma48 = value; return 0; }
     if (id == 48) { g_wgrad_dma48_x2 = value; return 0; }
-    if (id == 50) { g_conv_ring48 = value; return 0; }
-    if (id == 51) { g_ring48_mt = (value == 4) ? 4 : 2; return 0; }
     if (id == 52) { g_ring_grid = value > 0 ? value : 0; return 0; }
+    if (id == 53) { g_mfc_validate_ptrs = value ? 1 : 0; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }
@@ -1197,7 +1192,10 @@ static int wgrad_any(const mfc_wgrad_desc* d, void* stream, int* parts_only) {
     return wgrad_launch<float, 28, false>(k, lds, Y, st);
 }
 
-extern "C" int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream) { return wgrad_any(d, stream, nullptr); }
+extern "C" int mfc_conv2d_wgrad(const mfc_wgrad_desc* d, void* stream) {
+    if (d && !mfc_ptrs_ok(d->x, d->dy, d->dwp, d->in_coef)) return MFC_ERR_INVALID_ARG;
+    return wgrad_any(d, stream, nullptr);
+}
 
 extern "C" int mfc_conv2d_wgrad_parts(const mfc_wgrad_desc* d) {
     if (!d) return MFC_ERR_INVALID_ARG;

@@ -304,6 +304,8 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
     if (!mfc_dtype_ok(d->dtype)) return MFC_ERR_INVALID_ARG;
     if (!view_ok(d->out, E) || d->C <= 0 || d->C % E || d->N <= 0 || d->images_per_group <= 0) return MFC_ERR_INVALID_ARG;
     if (d->out.c_off + d->C > d->out.Cp) return MFC_ERR_INVALID_ARG;
+    if (!mfc_ptrs_ok(d->out.ptr, d->src[0].ptr, d->src[0].coef, d->src[1].ptr, d->src[1].coef, d->src[2].ptr, d->src[2].coef, d->src[3].ptr, d->src[3].coef,
+                     d->maskbits, d->fin)) return MFC_ERR_INVALID_ARG;
     for (int k = 0; k < d->nsrc; ++k)
         if (!view_ok(d->src[k], E) || d->src[k].c_off + d->C > d->src[k].Cp) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
@@ -481,6 +483,7 @@ static int bnbwd_check(const mfc_bnbwd_desc* d, int& E) {
 extern "C" int mfc_bnbwd_reduce(const mfc_bnbwd_desc* d, void* stream) {
     int E; int rc = bnbwd_check(d, E); if (rc < 0) return rc;
     if (!d->bstats) return MFC_ERR_INVALID_ARG;
+    if (!mfc_ptrs_ok(d->g.ptr, d->y.ptr, d->y.coef, d->mask.ptr, d->dy.ptr, d->bstats)) return MFC_ERR_INVALID_ARG;
     if (d->dy.ptr && (!view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W)) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
     if (Cg > 256) return MFC_ERR_UNSUPPORTED;
@@ -674,6 +677,7 @@ __global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, 
 extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
     int E; int rc = bnbwd_check(d, E); if (rc < 0) return rc;
     if (!view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W) return MFC_ERR_INVALID_ARG;
+    if (!mfc_ptrs_ok(d->g.ptr, d->y.ptr, d->y.coef, d->mask.ptr, d->dy.ptr, d->bstats, d->bcoef, d->fin_dgamma, d->fin_dbeta)) return MFC_ERR_INVALID_ARG;
     if (d->fin_dgamma) {       // finalize fused into this launch
         if (d->gn_mode) return MFC_ERR_UNSUPPORTED;
         const int G = d->N / d->images_per_group;
@@ -932,6 +936,7 @@ extern "C" int mfc_mask_add(const mfc_maskadd_desc* d, void* stream) {
     const int E = mfc_is16(d->dtype) ? 8 : 4;
     if (!view_ok(d->g, E) || !view_ok(d->dst, E) || d->C <= 0 || d->C % E || d->N <= 0) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode != 0 && d->mask_mode != 1 && d->mask_mode != 3) return MFC_ERR_INVALID_ARG;
+    if (!mfc_ptrs_ok(d->g.ptr, d->mask.ptr, d->dst.ptr, d->scratch)) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode == 1 && (!view_ok(d->mask, E) || d->mask.H != d->g.H || d->mask.W != d->g.W)) return MFC_ERR_INVALID_ARG;
     if (d->mask_mode == 3 && (!mfc_is16(d->dtype) || !d->mask.ptr || d->mask.Cp % 8 || d->mask.c_off % 8 || d->mask.H != d->g.H || d->mask.W != d->g.W)) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;

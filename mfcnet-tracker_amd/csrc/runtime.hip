@@ -287,6 +287,18 @@ static int adam_step_impl(float* p, const float* g, float* m, float* v, int64_t 
     return MFC_OK;
 }
 
+// ------------------------------------------------------------------ descriptor hardening (common.h)
+int g_mfc_validate_ptrs = 0;
+bool mfc_ptrs_ok_impl(const void* const* p, int n) {
+    for (int i = 0; i < n; ++i) {
+        if (!p[i]) continue;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p[i]) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeManaged) return false;
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------ event profiler
 // Rows are keyed by kernel NAME (the string rocprofv3 prints for that kernel, demangled), so bench.py's `roofline` object and the
 // committed rocprofv3 kernel-stats table talk about the same rows.

@@ -986,3 +986,34 @@ def test_invalid_descriptors_are_rejected(M):
     w = torch.zeros(8, 12, 3, 3, device="cuda")
     with pytest.raises(L.MfcError):
         ops.conv2d(x, w, 3, 1)
+
+
+def test_placeholder_pointers_are_refused_not_faulted():
+    """Round 3's aborts (gpurun_out/r03_t5.log, r03_t6.log): descriptors cloned from a DRY plan carried its placeholder address (1 << 30 + offset) in
+    mfc_conv_desc.in_fin / mfc_combine_desc.fin; bn_fold_prologue dereferenced it and the GPU faulted at the next synchronisation.  With the
+    descriptor hardening on (the GPU test session's default) such a launch is refused."""
+    from mfcnet_amd import _lib as L, ops
+    import ctypes as C
+    assert L.lib.mfc_set_flag(53, 1) == 0
+    x = torch.randn(2, 8, 8, 32, device="cuda").to(torch.bfloat16)
+    out = torch.zeros_like(x)
+    coef = torch.ones(1, 4, 32, device="cuda")
+    w = torch.randn(32, 32, 3, 3, device="cuda") * 0.1
+    d = L.ConvDesc(x.data_ptr(), 0, out.data_ptr(), 0, coef.data_ptr(), 0, L.BF16, 2, 8, 8, 32, 32, 8, 8, 32, 32, 8, 8, 3, 3, -1, -1, 1, 1, 1, 0, 0, 1, 2, 0, 0, 0)
+    wp = ops.pack_weight(w, d, "fwd")
+    d.wp = wp.data_ptr()
+    assert L.lib.mfc_conv2d_fwd(C.byref(d), L.stream_ptr()) == 0
+    d.in_fin = (1 << 30) + 4096                       # a dry plan's "fin" arena
+    assert L.lib.mfc_conv2d_fwd(C.byref(d), L.stream_ptr()) == -1
+    d.in_fin = 0
+    host = torch.zeros(64)
+    d.bias = host.data_ptr()                          # a host tensor's address
+    assert L.lib.mfc_conv2d_fwd(C.byref(d), L.stream_ptr()) == -1
+    cd = L.CombineDesc()
+    cd.out = L.View(out.data_ptr(), 0, 8, 8, 32, 0)
+    cd.src[0] = L.View(x.data_ptr(), 0, 8, 8, 32, 0)
+    cd.nsrc, cd.relu, cd.dtype, cd.N, cd.C, cd.images_per_group = 1, 1, L.BF16, 2, 32, 2
+    assert L.lib.mfc_combine_fwd(C.byref(cd), L.stream_ptr()) == 0
+    cd.fin = (1 << 30) + 128
+    assert L.lib.mfc_combine_fwd(C.byref(cd), L.stream_ptr()) == -1
+    torch.cuda.synchronize()

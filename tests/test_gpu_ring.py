@@ -38,13 +38,11 @@ def sign_bits(t_nhwc):
     return (b * w).sum(1).to(torch.uint8).contiguous()
 
 
-def run(L, ops, dtype, shape, variant, ring, mt=4, stream=0, ring48=0):
+def run(L, ops, dtype, shape, variant, ring, mt=4):
     N, Cc, H, W, G = shape
     ipg = N // G
     L.lib.mfc_set_flag(30, 1 if ring else 0)
     L.lib.mfc_set_flag(31, mt)
-    L.lib.mfc_set_flag(34, stream)
-    L.lib.mfc_set_flag(50, ring48)
     g = torch.Generator().manual_seed(11)
     rd = lambda *s: torch.randn(*s, generator=g).to(dtype).float()
     x = rd(N, Cc, H, W)
@@ -153,55 +151,3 @@ def test_ring_kernel_two_row_tiles(M, variant):
     assert (lay2.MT, lay4.MT) == (2, 4)
     assert torch.equal(o2, o4) and relerr(ops.to_nchw(o2, 32).cpu(), ref) < TOL[torch.bfloat16]
     assert relerr(s2.double(), s4.double()) < 1e-6
-
-
-STREAM_SHAPES = [(3, 128, 13, 21, 3), (6, 128, 30, 40, 3), (2, 256, 7, 20, 1), (4, 256, 15, 20, 2), (2, 128, 8, 8, 2)]
-
-
-@pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("shape", STREAM_SHAPES, ids=lambda s: "N%d_C%d_%dx%d_G%d" % s)
-def test_stream_kernel_vs_cpu_and_vs_igemm(M, shape, variant):
-    """conv3x3_stream_kernel (128 / 256 channels; off by default, mfc_set_flag(34, 1)): kept in the tree as a measured negative result, so
-    it stays held to the same two checks as the ring kernel."""
-    _, L, ops = M
-    Cc = shape[1]
-    dtype = torch.bfloat16
-    try:
-        o_s, s_s, ref, ref_s, lay_s = run(L, ops, dtype, shape, variant, ring=True, stream=1)
-        o_i, s_i, _, _, lay_i = run(L, ops, dtype, shape, variant, ring=True, stream=0)
-    finally:
-        L.lib.mfc_set_flag(34, 0)
-    if (lay_s.NT16, lay_s.nslots, lay_s.TAS) != (64, 12, 1):                         # (the stream kernel's weight blocking: did it run?)
-        pytest.skip("shape not taken by the stream kernel")
-    assert relerr(ops.to_nchw(o_s, Cc).cpu(), ref) < TOL[dtype]
-    assert torch.equal(o_s, o_i)
-    if ref_s is not None:
-        assert relerr(s_s[..., :Cc].float(), ref_s) < 5 * TOL[dtype]
-        assert relerr(s_s.double(), s_i.double()) < 1e-6
-
-
-C48_SHAPES = [(6, 48, 21, 37, 3), (3, 48, 7, 9, 1), (8, 48, 16, 16, 8), (2, 48, 33, 17, 2), (2, 48, 5, 40, 1), (3, 48, 40, 48, 3)]
-
-
-@pytest.mark.parametrize("variant", ["plain", "stats", "xf+stats", "acc"])
-@pytest.mark.parametrize("shape", C48_SHAPES, ids=lambda s: "N%d_C%d_%dx%d_G%d" % s)
-@pytest.mark.parametrize("dtype", H16, ids=["bf16", "fp16"])
-def test_ring48_kernel_vs_cpu_and_vs_igemm(M, dtype, shape, variant):
-    """conv3x3_ring48_kernel (48 -> 48: the BasicBlocks of HRNet-W48's 120x160 branch, hrnet.py:297-333; k = 32 + k = 16 MFMA steps per tap):
-    ragged shapes, 1-8 statistic groups, statistics / fused input transform / accumulate; against CPU fp32 operators and against
-    conv_igemm (mfc_set_flag(50, 0)), which adds the products up in another order (outputs equal to the storage type's rounding).
-    The kernel is OFF by default (slower than conv_igemm so far); it stays held to these checks."""
-    _, L, ops = M
-    Cc = shape[1]
-    try:
-        o_r, s_r, ref, ref_s, lay_r = run(L, ops, dtype, shape, variant, ring=True, ring48=1)
-        o_i, s_i, _, _, lay_i = run(L, ops, dtype, shape, variant, ring=True, ring48=0)
-    finally:
-        L.lib.mfc_set_flag(50, 0)
-    assert (lay_r.KG, lay_r.nslots, lay_r.NT16, lay_r.nchunks, lay_r.TW) == (6, 54, 48, 1, 16) and lay_r.TH in (8, 16)        # the ring48 layout
-    got = ops.to_nchw(o_r, Cc).cpu()
-    assert relerr(got, ref) < TOL[dtype], (variant, relerr(got, ref))
-    assert relerr(o_r.float(), o_i.float()) < TOL[dtype]
-    if ref_s is not None:
-        assert relerr(s_r[..., :Cc].float(), ref_s) < 5 * TOL[dtype]
-        assert relerr(s_r.double(), s_i.double()) < 1e-4

@@ -10,13 +10,12 @@ from mfcnet_amd import _lib as L, ops
 from sweep_conv2 import time_op
 
 G = 3
-SHAPES = [(24, 32, 120, 160), (24, 64, 60, 80), (24, 128, 30, 40), (24, 256, 15, 20), (12, 32, 120, 160), (24, 32, 45, 60), (24, 64, 23, 30), (40, 128, 45, 60), (12, 256, 23, 30)]
+SHAPES = [(24, 32, 120, 160), (24, 64, 60, 80), (12, 32, 120, 160), (24, 32, 45, 60), (24, 64, 23, 30)]
 VARIANTS = ["plain", "stats", "xf+stats", "acc", "bn2", "acc+src+bn3"]
 
 
 def build(N, Cc, H, W, variant, ring):
     L.lib.mfc_set_flag(30, 1 if ring else 0)
-    L.lib.mfc_set_flag(34, 1 if ring else 0)
     g = torch.Generator(device="cuda").manual_seed(7)
     x = torch.randn(N, H, W, Cc, device="cuda", generator=g).to(torch.bfloat16)
     w = torch.randn(Cc, Cc, 3, 3, device="cuda", generator=g) * 0.05
@@ -55,7 +54,7 @@ def build(N, Cc, H, W, variant, ring):
 def main():
     quick = "--quick" in sys.argv
     only = [a for a in sys.argv[1:] if a.startswith("C")]
-    for (N, Cc, H, W) in SHAPES[:4] if quick else SHAPES:
+    for (N, Cc, H, W) in SHAPES[:2] if quick else SHAPES:
         if only and f"C{Cc}" not in only:
             continue
         flops = 2.0 * N * H * W * Cc * Cc * 9
@@ -84,7 +83,7 @@ def main():
             serr = float((sa - sb).abs().max() / (sa.abs().max() + 1e-9)) if sa is not None else 0.0
             print(f"N{N} C{Cc} {H}x{W} {v:12s} igemm {ta:6.1f} us ({flops/ta/1e6:4.0f} TF, {byts/ta/1e3:5.0f} GB/s) | ring MT{lb.MT} grid{lb.grid}x{lb.per_block} "
                   f"{tb:6.1f} us ({flops/tb/1e6:4.0f} TF, {byts/tb/1e3:5.0f} GB/s) | max diff {err:.2e} stats {serr:.2e}", flush=True)
-    L.lib.mfc_set_flag(30, 1); L.lib.mfc_set_flag(34, 1)
+    L.lib.mfc_set_flag(30, 1)
 
 
 if __name__ == "__main__":
