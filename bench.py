@@ -55,7 +55,13 @@ def parse_args():
                     help="storage type of activations / packed weights (fp16: IEEE half with a static loss scale, BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the profiled step (no `roofline` object)")
-    ap.add_argument("--no-fp16-line", action="store_true", help="skip the fp16 side measurement of the default bf16 run (`fp16_storage` object)")
+    ap.add_argument("--fp16-line", action="store_true", help="also measure the same step with fp16 storage (`fp16_storage` object; opt-in since round 4: "
+                    "it builds and times a second model)")
+    ap.add_argument("--no-fp16-line", action="store_true", help="(accepted for old scripts: the fp16 side line is off unless --fp16-line)")
+    ap.add_argument("--no-fp32-parity", action="store_true", help="skip the `fp32_parity` side object (throughput of the fp32 parity mode + max |logits - oracle| "
+                    "on one clip; needs the CPU baseline leg, which evaluates the oracle's side of it)")
+    ap.add_argument("--weights", default="hash", choices=["hash", "init"], help="hash = key-hash generator of SURVEY.md 8(c)/(d) (the weights of the golden "
+                    "fixtures; default), init = torch's default initialisation from a fixed seed")
     ap.add_argument("--serial", action="store_true", help="one stream: no branch lanes / detached weight-gradient streams (for kernel profiles)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the data-parallel step path even with one rank "
@@ -153,7 +159,7 @@ def host_cpu():
     return model, os.cpu_count() or 1, usable
 
 
-def cpu_baseline(width, T, H, W):
+def cpu_baseline(width, T, H, W, parity_clip=False, optflow=False, depth=False):
     """The CPU oracle on the host cores, bounded samples: the MFCNet training step (the value), its
     eval-mode forward, and the single-frame HRNet B=2 training step that stands in for BASELINE configs[0]."""
     import torch
@@ -205,6 +211,14 @@ def cpu_baseline(width, T, H, W):
         loss.backward()
         so.step()
     t_single = timed(single_step, 3)
+    parity = None
+    if parity_clip:
+        # the oracle's half of `fp32_parity`: eval-mode logits of one hash-generated clip with the key-hash weights (the GPU side runs the same clip)
+        sdp = O.hashed_state(O.mfcnet_table("HRNetMulti-Large", width, 5, T, optflow, depth))
+        netp = O.Net(sdp, "HRNetMulti-Large", width, 5, T, optflow, depth).eval()
+        pf, pfl, pd, _ = O.synthetic_clip("bench/parity", 1, T, H, W, optflow, depth)
+        with torch.no_grad():
+            parity = {"inputs": (pf, pfl, pd), "logits": netp(pf, pfl, pd).float()}
     return {"value": round(T / t_step, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "host": {"cpu_model": model, "logical_cpus": logical, "usable_cpus": usable, "torch_threads": threads,
                      "threads_note": "32 of the host's cores: the B=1 convolutions of torch's CPU backend are SLOWER with more (measured 1.1 frames/s at 32 threads, 0.43 at 64)"},
@@ -214,7 +228,7 @@ def cpu_baseline(width, T, H, W):
             "fwd_only": {"value": round(T / t_fwd, 4), "unit": "frames/s", "sample": f"median of 5 eval-mode forwards of the same clip (B=1, T={T})"},
             "single_frame_b2_step": {"value": round(2 / t_single, 4), "unit": "frames/s",
                                      "sample": f"median of 3 full training steps of the single-frame HRNet-w48 (model_type 'HRNet'), B=2, {H}x{W}, fp32 "
-                                               "(stand-in for BASELINE.json configs[0])"}}
+                                               "(stand-in for BASELINE.json configs[0])"}}, parity
 
 
 def roofline_of(row, steps, dtype, traffic=(None, None)):
@@ -307,6 +321,9 @@ def main():
     else:
         model = cls(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype=args.dtype,
                     optflow_inputs=args.optflow, depth_inputs=args.depth)
+    if args.weights == "hash":
+        from mfcnet_amd.synth import fill_hashed
+        fill_hashed(model)                                      # every state_dict entry a pure function of its key
     model = model.to(device)
     model = model.eval() if args.fwd_only else model.train()
     for env, attr in (("MFC_MASK_BITS", "relu_mask_bits"), ("MFC_BATCH_WGRAD", "batch_wgrad"), ("MFC_FUSE_BNRED", "fuse_bnbwd_reduce")):      # tuning switches of the plan
@@ -399,12 +416,15 @@ def main():
         records = (len(plan.fwd_prog) + len(plan.bwd_prog)) if hasattr(plan, "bwd_prog") else None
     del plan
     fp16_side = None
-    if (world == 1 and args.dtype == "bf16" and not args.fwd_only and not args.no_fp16_line and not args.single and not args.serial
+    if (world == 1 and args.dtype == "bf16" and not args.fwd_only and args.fp16_line and not args.single and not args.serial
             and not os.environ.get("MFC_SKIP_KINDS")):
         del model, opt
         torch.cuda.empty_cache()
         m16 = cls(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype="fp16",
-                  optflow_inputs=args.optflow, depth_inputs=args.depth).to(device).train()
+                  optflow_inputs=args.optflow, depth_inputs=args.depth)
+        if args.weights == "hash":
+            fill_hashed(m16)
+        m16 = m16.to(device).train()
         o16 = mfc.FlatAdam(m16, lr=1e-4)
 
         def step16():
@@ -426,6 +446,48 @@ def main():
                      "why": "same kernels with IEEE-half storage and an adaptive loss scale; the fidelity of a 16-bit step is set by the rounding of the FORWARD "
                             "tensors (profiles/r03_fidelity_probe.txt), where fp16 keeps 3 more bits than bf16"}
         del m16, o16
+
+    # ---- CPU baseline leg (rank 0, N = 1): the oracle timed on the host cores; it also evaluates the ORACLE'S side of `fp32_parity`
+    #      (eval-mode logits of one hash-generated clip) -- the only place bench.py touches oracle/
+    cpu, parity_ref = None, None
+    want_parity = (world == 1 and rank == 0 and not args.no_cpu_baseline and not args.no_fp32_parity and args.dtype == "bf16" and not args.fwd_only
+                   and not args.single and not args.serial and not args.basic and not os.environ.get("MFC_SKIP_KINDS") and args.weights == "hash")
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu, parity_ref = cpu_baseline(args.width, T, H, W, parity_clip=want_parity, optflow=args.optflow, depth=args.depth)
+    fp32_parity = None
+    if want_parity and parity_ref is not None:
+        # the reference computes in fp32; north_star's 1e-3 logit bound is stated for that mode.  Its throughput on the same step
+        # and its distance from the CPU oracle on one clip ride beside the bf16 headline, so a driver record carries a number at the reference's precision
+        try:
+            del model, opt
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        m32 = cls(num_classes=nc, num_frames=T, pretrained=False, width=args.width, compute_dtype="fp32", optflow_inputs=args.optflow, depth_inputs=args.depth)
+        fill_hashed(m32)
+        m32 = m32.to(device).train()
+        o32 = mfc.FlatAdam(m32, lr=1e-4)
+        for _ in range(2):
+            mfc.train_step(m32, o32, frames, mask, optflow=flow, depth=depth)
+        n32 = 3
+        torch.cuda.synchronize()
+        t32 = time.perf_counter()
+        for _ in range(n32):
+            mfc.train_step(m32, o32, frames, mask, optflow=flow, depth=depth)
+        torch.cuda.synchronize()
+        t32 = time.perf_counter() - t32
+        fill_hashed(m32)                                        # (the timed steps moved the weights: back to the fixture state for the parity clip)
+        m32.eval()
+        pf, pfl, pd = parity_ref["inputs"]
+        with torch.no_grad():
+            yp = m32([f.to(device) for f in pf], optflow=[f.to(device) for f in pfl] if pfl else None, depth=[f.to(device) for f in pd] if pd else None)
+        err = float((yp.float().cpu() - parity_ref["logits"]).abs().max())
+        fp32_parity = {"value": round(B * T * n32 / t32, 2), "unit": "frames/s", "ms_per_step": round(t32 / n32 * 1e3, 2), "steps": n32, "dtype": "f32",
+                       "logits_max_abs_err_vs_oracle": err, "logits_abs_max": float(parity_ref["logits"].abs().max()), "bound": 1e-3,
+                       "clip": f"eval-mode forward of one hash-generated clip (B=1, T={T}, {H}x{W}, key-hash weights) against the CPU oracle's logits",
+                       "why": "the reference computes in fp32 and north_star's 1e-3 bound is stated for it: the same step in the fp32 parity mode "
+                              "(v_mfma_f32_16x16x4_f32: exact fp32 products, 1/16 of the bf16 MFMA rate) next to the bf16 headline"}
+        del m32, o32
 
     extra = ("+depth" if args.depth else "") + ("+optflow" if args.optflow else "")
     cfg_label = ("per-GPU share of BASELINE.json configs[3]" if (T, H, W, B, extra) == (3, 480, 640, 4, "+depth+optflow") else
@@ -497,8 +559,12 @@ def main():
                "roofline": roof, "roofline_top": roof_top, "roofline_conv": roof_conv}
         if fp16_side is not None:
             out["fp16_storage"] = fp16_side
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.width, T, H, W)
+        if fp32_parity is not None:
+            out["fp32_parity"] = fp32_parity
+        out["config"]["weights"] = "key-hash generator (SURVEY.md 8(c)/(d): every state_dict entry a pure function of its key; the golden fixtures' model)" \
+            if args.weights == "hash" else "torch default initialisation, manual_seed(1234)"
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

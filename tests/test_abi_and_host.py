@@ -234,3 +234,21 @@ def test_dry_plan_enumerates_the_benchmarked_launches_without_a_gpu():
     plf = Plan(m, 8, 480, 640, False, False, False, True, True, torch.device("cpu"), base_frozen=True, dry=True)
     assert len(plf.bwd) < 40 and not any(r[0] == _lib.OP_HEAD_BWD for r in plf.bwd)
     assert len(pl.bwd) > 1000
+
+
+def test_product_key_hash_generator_equals_the_oracles():
+    """mfcnet_amd.synth (bench.py's weights) against the oracle's `hashed_state`, entry by entry: same keys in the same order,
+    same bits -- for both model types (with flow / depth inputs: the Basic model's registered grid is kept, not generated) and the single-frame net."""
+    import mfcnet_amd as mfc
+    from mfcnet_amd.synth import fill_hashed, hashed_state_for
+    from oracle import mfcnet_oracle as O
+    for cls, mt, T, fl, dp, w in ((mfc.HRNetMultiLarge, "HRNetMulti-Large", 3, False, False, 32), (mfc.HRNetMultiBasic, "HRNetMulti-Basic", 3, True, True, 48)):
+        m = cls(num_classes=5, num_frames=T, pretrained=False, width=w, optflow_inputs=fl, depth_inputs=dp)
+        a, b = hashed_state_for(m), O.hashed_state(O.mfcnet_table(mt, w, 5, T, fl, dp))
+        assert list(a) == list(b)
+        assert all(torch.equal(a[k], b[k]) for k in a), [k for k in a if not torch.equal(a[k], b[k])][:3]
+    s = mfc.HighResolutionNetHIP(num_classes=5, width=48)
+    a, b = hashed_state_for(s), O.hashed_state(O.hrnet_table(48, 5, ""))
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    fill_hashed(s)
+    assert torch.equal(s.state_dict()["conv1.weight"], b["conv1.weight"])

@@ -34,7 +34,7 @@ def _json_line(out):
 
 def test_bench_line_contract():
     _need_gpu()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--fp16-line"] + SMALL, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -62,6 +62,21 @@ def test_bench_line_contract():
     assert d["roofline"]["profiled_step_streams"].startswith("serial")
     assert 0.0 < d["config"]["final_loss"] < 20.0
     assert d["config"]["launcher"] == "bench.py" and d["config"]["ranks"] == 1
+    assert "key-hash" in d["config"]["weights"] and "fp32_parity" not in d and "cpu_baseline" not in d          # (--no-cpu-baseline: no oracle leg at all)
+
+
+def test_bench_fp32_parity_and_cpu_baseline_objects():
+    """The default line's side objects: `cpu_baseline` (the oracle timed on the host cores) and `fp32_parity` -- the same
+    step in the fp32 parity mode (frames/s) and max |logits - oracle| of one hash-generated clip, which must meet north_star's 1e-3."""
+    _need_gpu()
+    small = [a for a in SMALL if a != "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-prof"] + small, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    cb, fp = d["cpu_baseline"], d["fp32_parity"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s"
+    assert fp["value"] > 0 and fp["dtype"] == "f32" and 0.0 <= fp["logits_max_abs_err_vs_oracle"] < 1e-3 and fp["logits_abs_max"] > 0.01
+    assert "fp16_storage" not in d and d["dtype"] == "bf16"
 
 
 def test_bench_fp16_line():

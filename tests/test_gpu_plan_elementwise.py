@@ -205,6 +205,7 @@ def run_apply(d0, L, gen):
         bco[:, 0, ys], bco[:, 1, ys] = c1, c2
         bcod = bco.cuda()
         d.bcoef = bcod.data_ptr()
+        d.bstats = 0                # (unused with explicit coefficients; the dry plan's placeholder must not travel -- descriptor hardening refuses it)
         keep.append(bcod)
     if alias:
         out_d = t["g_d"]
