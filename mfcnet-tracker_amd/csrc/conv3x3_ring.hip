@@ -67,6 +67,20 @@ __device__ __attribute__((aligned(16))) const unsigned r_zero16[4] = {0u, 0u, 0u
 __device__ inline void r_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// 16-byte output store.  mode 0: plain (write-back: the line stays dirty in the XCD's L2 until it is evicted or the end-of-kernel release writes it
+// back); 1: sc1 = write-through (the bytes leave for memory at once and the line is dropped: nothing is left for the kernel boundary to flush);
+// 2: nt.  Experiment of round 4 (mfc_set_flag(32, 32 | 64)): MI355X_MICROARCH.md prices a boundary at + dirty bytes / 6 TB/s.
+__device__ inline void r_store16(char* addr, uint4 v, int mode) {
+    if (mode == 1) {
+        const u32x4 d = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(addr), "v"(d) : "memory");
+    } else if (mode == 2) {
+        __builtin_nontemporal_store(v.x, (unsigned*)addr); __builtin_nontemporal_store(v.y, (unsigned*)addr + 1);
+        __builtin_nontemporal_store(v.z, (unsigned*)addr + 2); __builtin_nontemporal_store(v.w, (unsigned*)addr + 3);
+    } else {
+        *(uint4*)addr = v;
+    }
+}
 constexpr int R_PW = 18;                    // patch width: 16-pixel tile rows + halo
 constexpr int R_NSLOT = 3;                  // ring slots
 
@@ -216,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
                 for (int nt = 0; nt < 2; ++nt)
                     wr[t][kc][nt] = *(const bf16x8*)(ws + ((size_t)((t * KG + kc * 4) * C) + nt * 16) * 16);
     }
+    const int st_mode = (p.ablate & 32) ? 1 : ((p.ablate & 64) ? 2 : 0);
     const bool xf = (p.in_coef != nullptr);
     if (xf) {
         for (int i = tid; i < p.G * 2 * C; i += 256) {
@@ -509,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
                             for (int r = 0; r < 4; ++r)
                                 if (vpx) { ssum[nt][r] += v[nt][r]; ssq[nt][r] += v[nt][r] * v[nt][r]; }
                     }
-                    if (vpx) *(uint4*)(tbase + (unsigned)(e_lane + mt * e_row)) = make_uint4(a16[0], b16[0], a16[1], b16[1]);
+                    if (vpx) r_store16(tbase + (unsigned)(e_lane + mt * e_row), make_uint4(a16[0], b16[0], a16[1], b16[1]), st_mode);
                 }
             }
             if (p.out_stats) {
