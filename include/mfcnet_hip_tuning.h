@@ -42,7 +42,8 @@ extern "C" {
  *  50-51  (round 3's conv3x3_ring48.hip: removed in round 4 -- measured slower)
  *  52  ring kernel: workgroups per launch (0 = 256 x switch 33; probes of partitioned grids, tools/probe_group.py)
  *  53  descriptor hardening (0): 1 = every non-null pointer of a convolution / weight-gradient / combine / BatchNorm-backward / mask-add descriptor is checked with
- *      hipPointerGetAttributes before the launch (MFC_ERR_INVALID_ARG for host or unmapped addresses instead of a GPU fault); the -m gpu tests run with it on */
+ *      hipPointerGetAttributes before the launch (MFC_ERR_INVALID_ARG for host or unmapped addresses instead of a GPU fault); the -m gpu tests run with it on
+ *  54  write-through (sc1) 16-byte output stores from this many MB of output per launch (12; 0 = plain stores everywhere): mfcnet-tracker_amd/csrc/common.h, mfc_st16 */
 int mfc_set_flag(int id, int value);
 #ifdef __cplusplus
 }

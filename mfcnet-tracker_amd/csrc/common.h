@@ -111,6 +111,38 @@ template <> __device__ inline void st_elem<float>(float* p, float v) { *p = v; }
 template <> __device__ inline void st_elem<bf16_t>(bf16_t* p, float v) { *p = (bf16_t)v; }
 template <> __device__ inline void st_elem<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 
+// 16-byte store of an OUTPUT tensor.  A plain store leaves its line dirty in the XCD's L2 until it is evicted or the end-of-kernel release writes
+// it back, and a kernel boundary costs + (dirty bytes) / 6 TB/s on top of its fixed part (MI355X_MICROARCH.md, "boundary"): a launch that
+// writes a 15-30 MB tensor ends with most of the XCDs' 32 MB of L2 dirty.  `sc1` makes the store WRITE-THROUGH: the bytes leave for memory while
+// the kernel is still running and nothing is left to flush (the line is dropped from L2, which the next launch -- another kernel, whose reads
+// miss the non-coherent L2s anyway -- does not care about).  Measured on the ring convolution, 20 dependent launches (tools/probe_store.py,
+// profiles/r04_store_flavours.txt): 32 -> 32 at 120x160 20.5 -> 18.4 us, 64 -> 64 at 60x80 17.4 -> 16.1 us; `nt` stores change nothing.
+// Only 16-byte stores: narrower sc1 stores are one fabric write each (2.7x / 6x the time per byte for 8 / 4 bytes, same source).
+// Inline asm because hipcc has no builtin for the sc1 bit on a global store; the trailing s_nop keeps the data registers intact until the
+// store has read them (cdna_hip_programming.md 5.7).  -DMFC_PLAIN_STORES builds the write-back form for A/B runs.
+typedef __attribute__((ext_vector_type(4))) unsigned mfc_u32x4;
+__device__ inline void mfc_st16(void* addr, uint4 v) {
+#ifdef MFC_PLAIN_STORES
+    *(uint4*)addr = v;
+#else
+    const mfc_u32x4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(addr), "v"(d) : "memory");
+#endif
+}
+
+// The write-through form pays only where the output is large: a small tensor (the 30x40 / 15x20 branches, 4-7 MB) stays resident in the XCDs' L2s
+// across the kernel boundary and the consumer -- same XCD-contiguous tile order -- hits it there, which sc1 (the line is dropped) gives up.
+// Measured per kernel family on the serial step (profiles/r04_store_flavours.txt): ring convolutions 5.34 -> 5.02 ms, bnbwd_apply_fin 4.38 ->
+// 4.14, combine_same 2.09 -> 1.98 with sc1; conv_igemm (mostly small tensors) 15.77 -> 16.03 and the two-pass up-sampling adjoint (its fp32
+// scratch is re-read at once) 1.11 -> 1.26 the other way.  So the launchers choose per launch: write-through from g_mfc_wt_min_mb megabytes of
+// output (mfc_set_flag(54, MB); 0 = never), and kernels whose output is re-read immediately keep plain stores.
+extern int g_mfc_wt_min_mb;
+static inline int mfc_wt_for(double out_bytes) { return g_mfc_wt_min_mb > 0 && out_bytes >= (double)g_mfc_wt_min_mb * 1048576.0; }
+__device__ inline void mfc_st16_if(void* addr, uint4 v, int wt) {        // wt is wave-uniform (a kernel argument)
+    if (wt) mfc_st16(addr, v);
+    else *(uint4*)addr = v;
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
 // logical ids so neighbouring tiles (shared halos / shared input patch across cout blocks)
 // hit the same L2.  Bijective for any nwg (guide T1).  Speed only, never correctness.

@@ -40,6 +40,7 @@ struct RingK {
     int tilesY, tilesX, ntiles, per_block;
     int off_coef, off_bnc, off_red;          // LDS byte offsets behind the ring
     int stagger;                             // cycles the SECOND workgroup of a CU waits before it starts (de-phases the two; mfc_set_flag(37, cycles))
+    int wt;                                  // write-through output stores (common.h: large outputs only)
     int ablate;                              // tuning only (mfc_set_flag(32, mask)): 1 skip MFMAs, 2 skip stores, 4 skip DMA, 8 skip fix-up, 16 skip statistics
 };
 
@@ -67,18 +68,15 @@ __device__ __attribute__((aligned(16))) const unsigned r_zero16[4] = {0u, 0u, 0u
 __device__ inline void r_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-// 16-byte output store.  mode 0: plain (write-back: the line stays dirty in the XCD's L2 until it is evicted or the end-of-kernel release writes it
-// back); 1: sc1 = write-through (the bytes leave for memory at once and the line is dropped: nothing is left for the kernel boundary to flush);
-// 2: nt.  Experiment of round 4 (mfc_set_flag(32, 32 | 64)): MI355X_MICROARCH.md prices a boundary at + dirty bytes / 6 TB/s.
+// output store of the plain epilogue: write-through (common.h, mfc_st16) unless the ablation mask asks for the write-back (32) or nt (64) form
 __device__ inline void r_store16(char* addr, uint4 v, int mode) {
     if (mode == 1) {
-        const u32x4 d = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(addr), "v"(d) : "memory");
+        *(uint4*)addr = v;
     } else if (mode == 2) {
         __builtin_nontemporal_store(v.x, (unsigned*)addr); __builtin_nontemporal_store(v.y, (unsigned*)addr + 1);
         __builtin_nontemporal_store(v.z, (unsigned*)addr + 2); __builtin_nontemporal_store(v.w, (unsigned*)addr + 3);
     } else {
-        *(uint4*)addr = v;
+        mfc_st16(addr, v);
     }
 }
 constexpr int R_PW = 18;                    // patch width: 16-pixel tile rows + halo
@@ -230,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
                 for (int nt = 0; nt < 2; ++nt)
                     wr[t][kc][nt] = *(const bf16x8*)(ws + ((size_t)((t * KG + kc * 4) * C) + nt * 16) * 16);
     }
-    const int st_mode = (p.ablate & 32) ? 1 : ((p.ablate & 64) ? 2 : 0);
+    const int st_mode = ((p.ablate & 32) || !p.wt) ? 1 : ((p.ablate & 64) ? 2 : 0);
     const bool xf = (p.in_coef != nullptr);
     if (xf) {
         for (int i = tid; i < p.G * 2 * C; i += 256) {
@@ -481,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
                                 }
                             }
                         }
-                        if (vpx) *(uint4*)(tbase + off) = Gran<T>::pack(w);
+                        if (vpx) mfc_st16_if((tbase + off), Gran<T>::pack(w), p.wt);
                         continue;
                     }
                     // (a FUSE launch without accumulate / bn_y stores like the plain kernel)
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
                             for (int r = 0; r < 4; ++r)
                                 if (vpx) { ssum[nt][r] += v[nt][r]; ssq[nt][r] += v[nt][r] * v[nt][r]; }
                     }
-                    if (vpx) *(uint4*)(tbase + off) = make_uint4(a16[0], b16[0], a16[1], b16[1]);
+                    if (vpx) mfc_st16_if((tbase + off), make_uint4(a16[0], b16[0], a16[1], b16[1]), p.wt);
                 }
             } else {
 #pragma unroll
@@ -587,6 +585,7 @@ static int ring_setup(const mfc_conv_desc* d, RingK& k, size_t& lds, int& grid, 
     k.in_relu = d->in_relu; k.ipg = d->images_per_group; k.G = d->N / d->images_per_group; k.accumulate = d->accumulate; k.bn_mode = d->bn_mask_mode;
     MT = g_ring_mt;
     k.ablate = g_ring_ablate; k.stagger = g_ring_stagger;
+    k.wt = mfc_wt_for((double)d->N * d->Hout * d->Wout * d->Cout_p * 2.0);
     if (d->Cin == 32) { if (MT == 4) ring_geo<1, 4>(d, k, lds, grid); else ring_geo<1, 2>(d, k, lds, grid); }
     else { MT = 4; ring_geo<2, 4>(d, k, lds, grid); }
     return MFC_OK;

@@ -41,6 +41,7 @@ struct ConvK {
     int off_dummy;                           // 16-byte LDS slot dead staging pieces are stored to
     int ybfast;                              // unit order: 1 = cout block fastest (the Yblocks units of a pixel tile run back to back on one workgroup: the re-reads of the tile hit L2 instead of HBM)
     int wres;                                // >0: single-stage launch whose Yblocks weight stages ALL stay in LDS (wres = Yblocks); the pixel tile is staged once for its Yblocks units
+    int wt;                                  // write-through output stores (common.h: large outputs only)
     int ablate;                              // tuning only: 1 skip weight DMA, 2 skip patch staging, 4 skip output stores, 8 skip MFMAs
     // data-gradient epilogue fusions (bf16 FA variants; include/mfcnet_hip.h): accumulate from another tensor; BatchNorm-backward statistics
     const char* acc_src; const char* bn_y; const float* bn_coef; const unsigned char* bn_bits; int bn_mode;
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                                         if (vpx && (n0 + (2 * pr + 1) * 16 + cq) < p.Cout_p) { ssum[2 * pr + 1][r] += v[2 * pr + 1][r]; ssq[2 * pr + 1][r] += v[2 * pr + 1][r] * v[2 * pr + 1][r]; }
                                     }
                                 }
-                                if (vpx && vc && !(p.ablate & 4)) *(uint4*)(tbase + off) = Gran<T>::pack(w);
+                                if (vpx && vc && !(p.ablate & 4)) mfc_st16_if((tbase + off), Gran<T>::pack(w), p.wt);
                             } else {
                                 const unsigned p0 = pack2<T>(v[2 * pr][0], v[2 * pr][1]), p1 = pack2<T>(v[2 * pr][2], v[2 * pr][3]);
                                 const unsigned q0 = pack2<T>(v[2 * pr + 1][0], v[2 * pr + 1][1]), q1 = pack2<T>(v[2 * pr + 1][2], v[2 * pr + 1][3]);
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                                         if (vpx && (n0 + (2 * pr + 1) * 16 + cq) < p.Cout_p) { ssum[2 * pr + 1][r] += v[2 * pr + 1][r]; ssq[2 * pr + 1][r] += v[2 * pr + 1][r] * v[2 * pr + 1][r]; }
                                     }
                                 }
-                                if (vpx && vc && !(p.ablate & 4)) *(uint4*)(tbase + off) = make_uint4(a16[0], b16[0], a16[1], b16[1]);
+                                if (vpx && vc && !(p.ablate & 4)) mfc_st16_if((tbase + off), make_uint4(a16[0], b16[0], a16[1], b16[1]), p.wt);
                             }
                         }
                     }
@@ -785,6 +786,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     k.ntiles = k.N * k.tilesY * k.tilesX;
     k.nunits = k.ntiles * k.Yblocks;
     k.ablate = g_conv_ablate;
+    k.wt = 0;          // (measured: this family is SLOWER with write-through stores at every threshold -- 15.78 -> 16.05 ms per serial step; common.h)
     {   // cout-block-fastest order when the Yblocks passes over the input would otherwise each stream it from HBM again
         const double in_bytes = (double)k.N * k.Hin * k.Win * k.Cin_p * (mfc_is16(d->dtype) ? 2.0 : 4.0);
         k.ybfast = g_conv_ybfast >= 0 ? (g_conv_ybfast && k.Yblocks > 1) : (k.Yblocks > 1 && in_bytes * (k.Yblocks - 1) > 128e6);

@@ -88,6 +88,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 48) { g_wgrad_dma48_x2 = value; return 0; }
     if (id == 52) { g_ring_grid = value > 0 ? value : 0; return 0; }
     if (id == 53) { g_mfc_validate_ptrs = value ? 1 : 0; return 0; }
+    if (id == 54) { g_mfc_wt_min_mb = value > 0 ? value : 0; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
     return MFC_ERR_INVALID_ARG;
 }

@@ -113,7 +113,7 @@ __device__ inline void load_gran_f(const mfc_view& v, int n, int h, int w, int c
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, long total, int Cg) {
+__global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, long total, int Cg, int wt) {
     constexpr int E = Gran<T>::E;
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // (host guarantees total < 2^31: 32-bit index arithmetic)
     if (idx >= (unsigned)total) return;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, lo
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = silu_f(acc[e]);
     }
-    *(uint4*)((char*)d.out.ptr + ((((size_t)n * d.out.H + h) * d.out.W + w) * d.out.Cp + d.out.c_off + g * E) * sizeof(T)) = Gran<T>::pack(acc);
+    mfc_st16_if(((char*)d.out.ptr + ((((size_t)n * d.out.H + h) * d.out.W + w) * d.out.Cp + d.out.c_off + g * E) * sizeof(T)), Gran<T>::pack(acc), wt);
     if constexpr (E == 8) {
         if (d.maskbits) {
             unsigned b = 0;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(mfc_combine_desc d, lo
 // all sources at the output resolution (residual blocks, BN materialisation): linear pixel index, 2 granules per thread
 // all sources at the output's resolution (residual adds, BatchNorm apply + ReLU): one-shot workgroups of 512 granules
 template <typename T>
-__global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, long total, int Cg) {
+__global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, long total, int Cg, int wt) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 2;
     const unsigned base = (blockIdx.x * 256u) * U + threadIdx.x;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, l
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] = silu_f(acc[e]);
         }
-        *(uint4*)((char*)d.out.ptr + ((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(acc);
+        mfc_st16_if(((char*)d.out.ptr + ((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) * sizeof(T)), Gran<T>::pack(acc), wt);
         if constexpr (E == 8) {
             if (d.maskbits) {       // the ReLU mask of the backward pass: one bit per element
                 unsigned b = 0;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, l
 // before the finalize, whose dependent replica reads then run under them.  (Without a finalize the one-shot form above is faster:
 // 17.8 vs 22.6 us on a 32-channel 120x160 tensor -- twice the waves in flight per CU.)
 template <typename T>
-__global__ __launch_bounds__(256) void combine_same_fin_kernel(mfc_combine_desc d, unsigned total, int Cg, unsigned per_block) {
+__global__ __launch_bounds__(256) void combine_same_fin_kernel(mfc_combine_desc d, unsigned total, int Cg, unsigned per_block, int wt) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 4;
     const unsigned lo = blockIdx.x * per_block;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void combine_same_fin_kernel(mfc_combine_desc 
 #pragma unroll
                 for (int e = 0; e < E; ++e) acc[e] = silu_f(acc[e]);
             }
-            *(uint4*)((char*)d.out.ptr + ((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(acc);
+            mfc_st16_if(((char*)d.out.ptr + ((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) * sizeof(T)), Gran<T>::pack(acc), wt);
             if constexpr (E == 8) {
                 if (d.maskbits) {       // the ReLU mask of the backward pass: one bit per element
                     unsigned b = 0;
@@ -317,6 +317,7 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
     for (int k = 0; k < d->nsrc; ++k) same = same && d->src[k].H == d->out.H && d->src[k].W == d->out.W;
     double cbytes = view_bytes(d->out, d->N, d->C, E == 8 ? 2 : 4) + (d->maskbits ? (double)total : 0.0);
     for (int k = 0; k < d->nsrc; ++k) cbytes += view_bytes(d->src[k], d->N, d->C, E == 8 ? 2 : 4);
+    const int wt = mfc_wt_for((double)total * 16.0);                 // write-through stores for a large output (common.h)
     if (d->fin && (!same || d->C > 256)) return MFC_ERR_UNSUPPORTED;     // the folded finalize lives in the same-resolution kernel
     if (same && d->fin) {
         const long nch = (total + 1023) / 1024;
@@ -324,7 +325,7 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
         const unsigned per_block = (unsigned)(((total + b2 - 1) / b2 + 7) / 8 * 8);
         b2 = (int)((total + per_block - 1) / per_block);
         EW_PROF(st, "combine_same_fin_kernel", d->dtype, cbytes);
-        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(combine_same_fin_kernel<T_>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg, per_block));
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(combine_same_fin_kernel<T_>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg, per_block, wt));
         MFC_PROF_END(st);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
@@ -332,13 +333,13 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
     if (same) {
         const int b2 = (int)((total + 511) / 512);
         EW_PROF(st, "combine_same_kernel", d->dtype, cbytes);
-        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(combine_same_kernel<T_>, dim3(b2), dim3(256), 0, st, *d, total, Cg));
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(combine_same_kernel<T_>, dim3(b2), dim3(256), 0, st, *d, total, Cg, wt));
         MFC_PROF_END(st);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
     }
     EW_PROF(st, "combine_fwd_kernel", d->dtype, cbytes);
-    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(combine_fwd_kernel<T_>, dim3(blocks), dim3(256), 0, st, *d, total, Cg));
+    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(combine_fwd_kernel<T_>, dim3(blocks), dim3(256), 0, st, *d, total, Cg, wt));
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(BS) void bnbwd_reduce_kernel(mfc_bnbwd_desc d, int 
 #pragma unroll
                         for (int e = 0; e < E; ++e) gm[e] += old[e];
                     }
-                    *(uint4*)o = Gran<T>::pack(gm);
+                    *(uint4*)(o) = Gran<T>::pack(gm);
                 }
             }
         }
@@ -558,7 +559,7 @@ extern "C" int mfc_bnbwd_finalize(const mfc_bnbwdfin_desc* d, void* stream) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long total, int Cg) {
+__global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long total, int Cg, int wt) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 4;                                   // granules in flight per thread
     const unsigned base = (blockIdx.x * 256u) * U + threadIdx.x;      // (host guarantees total < 2^31)
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long
             const float yh = (yv[e] - mu[e]) * rs[e];
             o[e] = d.gn_mode ? (cf[e] * gm[e] - rs[e] * (b1[e] + yh * b2[e])) : cf[e] * (gm[e] - b1[e] - yh * b2[e]);
         }
-        *(uint4*)((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(o);
+        mfc_st16_if(((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)), Gran<T>::pack(o), wt);
     }
 }
 
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(mfc_bnbwd_desc d, long
 // and the loads of its first 1024 granules are issued BEFORE the prologue, whose dependent fp64 replica reads (2-3 us of latency at
 // the head of a 10-25 us launch) then run under them.
 template <typename T>
-__global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, unsigned total, int Cg, int G, unsigned per_block) {
+__global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, unsigned total, int Cg, int G, unsigned per_block, int wt) {
     constexpr int E = Gran<T>::E;
     constexpr int U = 4;
     __shared__ float lbc[8 * 2 * 128];               // [g][stat][c] (G <= 8, C <= 128): c1 = mean(g*m), c2 = mean(g*m*yhat)
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256) void bnbwd_apply_fin_kernel(mfc_bnbwd_desc d, 
                 const float yh = (yv[e] - mu[e]) * rs[e];
                 o[e] = cf[e] * (gm[e] - b1[e] - yh * b2[e]);
             }
-            *(uint4*)((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(o);
+            mfc_st16_if(((char*)d.dy.ptr + ((size_t)pix[u] * d.dy.Cp + d.dy.c_off + gq[u] * E) * sizeof(T)), Gran<T>::pack(o), wt);
         }
         base += 256u * U;
         if (base - threadIdx.x >= hi) break;          // (block-uniform)
@@ -678,6 +679,7 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
     int E; int rc = bnbwd_check(d, E); if (rc < 0) return rc;
     if (!view_ok(d->dy, E) || d->dy.H != d->y.H || d->dy.W != d->y.W) return MFC_ERR_INVALID_ARG;
     if (!mfc_ptrs_ok(d->g.ptr, d->y.ptr, d->y.coef, d->mask.ptr, d->dy.ptr, d->bstats, d->bcoef, d->fin_dgamma, d->fin_dbeta)) return MFC_ERR_INVALID_ARG;
+    const int wt = mfc_wt_for((double)d->N * d->y.H * d->y.W * d->C * (E == 8 ? 2.0 : 4.0));      // write-through stores for a large output (common.h)
     if (d->fin_dgamma) {       // finalize fused into this launch
         if (d->gn_mode) return MFC_ERR_UNSUPPORTED;
         const int G = d->N / d->images_per_group;
@@ -691,7 +693,7 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
         grid = (int)((tot + per_block - 1) / per_block);
         hipStream_t s2 = (hipStream_t)stream;
         EW_PROF(s2, "bnbwd_apply_fin_kernel", d->dtype, (double)tot * 16.0 * (3 + (d->mask_mode == 1 ? 1 : 0)) + (d->mask_mode == 3 ? (double)tot : 0.0));
-        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_apply_fin_kernel<T_>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, per_block));
+        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_apply_fin_kernel<T_>, dim3(grid), dim3(256), 0, s2, *d, (unsigned)tot, Cgf, G, per_block, wt));
         MFC_PROF_END(s2);
         MFC_CHECK_LAUNCH();
         return MFC_OK;
@@ -703,7 +705,7 @@ extern "C" int mfc_bnbwd_apply(const mfc_bnbwd_desc* d, void* stream) {
     const int blocks = (int)((total + 1023) / 1024);
     hipStream_t st = (hipStream_t)stream;
     EW_PROF(st, "bnbwd_apply_kernel", d->dtype, (double)total * 16.0 * (3 + (d->mask_mode == 1 ? 1 : 0)) + (d->mask_mode == 3 ? (double)total : 0.0));
-    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_apply_kernel<T_>, dim3(blocks), dim3(256), 0, st, *d, total, Cg));
+    MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(bnbwd_apply_kernel<T_>, dim3(blocks), dim3(256), 0, st, *d, total, Cg, wt));
     MFC_PROF_END(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(256) void mask_add_kernel(mfc_maskadd_desc d, long 
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] += old[e];
     }
-    *(uint4*)o = Gran<T>::pack(acc);
+    *(uint4*)(o) = Gran<T>::pack(acc);
 }
 
 // Separable form of the same adjoint (the bilinear weights are a product of a row and a column factor):
@@ -849,7 +851,7 @@ __global__ __launch_bounds__(256) void mask_add_wpass_kernel(mfc_maskadd_desc d,
     }
     float* o = d.scratch + (size_t)idx * E;
 #pragma unroll
-    for (int e = 0; e < E; e += 4) *(float4*)(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+    for (int e = 0; e < E; e += 4) *(uint4*)(o + e) = make_uint4(__float_as_uint(acc[e]), __float_as_uint(acc[e + 1]), __float_as_uint(acc[e + 2]), __float_as_uint(acc[e + 3]));
 }
 
 template <typename T>
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(256) void mask_add_hpass_kernel(mfc_maskadd_desc d,
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] += old[e];
     }
-    *(uint4*)o = Gran<T>::pack(acc);
+    *(uint4*)(o) = Gran<T>::pack(acc);
 }
 
 // same-resolution fast path: linear pixel index, 4 granules in flight per thread
@@ -927,7 +929,7 @@ __global__ __launch_bounds__(256) void mask_add_same_kernel(mfc_maskadd_desc d, 
 #pragma unroll
             for (int e = 0; e < E; ++e) gv[e] += o[e];
         }
-        *(uint4*)((char*)d.dst.ptr + ((size_t)pix[u] * d.dst.Cp + d.dst.c_off + gq[u] * E) * sizeof(T)) = Gran<T>::pack(gv);
+        *(uint4*)(((char*)d.dst.ptr + ((size_t)pix[u] * d.dst.Cp + d.dst.c_off + gq[u] * E) * sizeof(T))) = Gran<T>::pack(gv);
     }
 }
 
@@ -1083,7 +1085,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, T* 
             const int c = g * E + e;
             f[e] = c < C ? src[((size_t)n * C + c) * HW + r] : 0.f;
         }
-        *(uint4*)((char*)dst + ((size_t)idx * Cp + c_off + g * E) * sizeof(T)) = Gran<T>::pack(f);
+        mfc_st16(((char*)dst + ((size_t)idx * Cp + c_off + g * E) * sizeof(T)), Gran<T>::pack(f));
     }
 }
 
@@ -1205,7 +1207,7 @@ __global__ __launch_bounds__(256) void head_gather_fwd_kernel(mfc_headgather_des
         }
     }
     for (int g = 0; g < Cp / E; ++g)
-        *(uint4*)((char*)d.xh + ((size_t)idx * Cp + g * E) * sizeof(T)) = Gran<T>::pack(v + g * E);
+        mfc_st16(((char*)d.xh + ((size_t)idx * Cp + g * E) * sizeof(T)), Gran<T>::pack(v + g * E));
 }
 
 static int head_check(const mfc_headgather_desc* d) {
@@ -1341,7 +1343,7 @@ __global__ __launch_bounds__(256) void head_gather_bwd_kernel(mfc_headgather_des
             float z[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) z[e] = (g * E + e) < 8 ? o[(g * E + e) & 7] : 0.f;
-            *(uint4*)((char*)op + g * 16) = Gran<T>::pack(z);
+            *(uint4*)(((char*)op + g * 16)) = Gran<T>::pack(z);
         }
     }
 }
@@ -1441,7 +1443,7 @@ __global__ __launch_bounds__(256) void upsample_nearest2x_kernel(const char* src
     const int g = (int)(idx % Cg); long pix = idx / Cg;
     const int w = (int)(pix % (2 * W)); pix /= (2 * W);
     const int h = (int)(pix % (2 * H)); const long n = pix / (2 * H);
-    *(uint4*)(dst + idx * 16) = *(const uint4*)(src + ((((size_t)n * H + (h >> 1)) * W + (w >> 1)) * Cg + g) * 16);
+    *(uint4*)((dst + idx * 16)) = *(const uint4*)(src + ((((size_t)n * H + (h >> 1)) * W + (w >> 1)) * Cg + g) * 16);
 }
 extern "C" int mfc_upsample_nearest2x(const void* src, void* dst, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t Cp, void* stream) {
     if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || Cp <= 0 || Cp % 8 || (!mfc_dtype_ok(dtype))) return MFC_ERR_INVALID_ARG;
@@ -1559,7 +1561,7 @@ __global__ __launch_bounds__(256) void upsample_nearest2x_bwd_kernel(const char*
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] += f[e];
         }
-    *(uint4*)(dst + idx * 16) = Gran<T>::pack(acc);
+    *(uint4*)((dst + idx * 16)) = Gran<T>::pack(acc);
 }
 extern "C" int mfc_upsample_nearest2x_bwd(const void* dsrc, void* ddst, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t Cp, int32_t accumulate, void* stream) {
     if (!dsrc || !ddst || N <= 0 || H <= 0 || W <= 0 || Cp <= 0 || Cp % 8 || (!mfc_dtype_ok(dtype))) return MFC_ERR_INVALID_ARG;

@@ -289,6 +289,7 @@ static int adam_step_impl(float* p, const float* g, float* m, float* v, int64_t 
 
 // ------------------------------------------------------------------ descriptor hardening (common.h)
 int g_mfc_validate_ptrs = 0;
+int g_mfc_wt_min_mb = 12;             // write-through output stores from this many megabytes of output (common.h, mfc_st16); mfc_set_flag(54, MB)
 bool mfc_ptrs_ok_impl(const void* const* p, int n) {
     for (int i = 0; i < n; ++i) {
         if (!p[i]) continue;

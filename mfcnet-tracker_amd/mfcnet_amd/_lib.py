@@ -14,7 +14,7 @@ import torch  # noqa: F401  MUST precede the CDLL below: PyTorch bundles its own
 #                     live in the same HIP runtime instance as our launches.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfcnet_hip.so")
+LIB_PATH = os.environ.get("MFC_LIB") or os.path.join(_HERE, "libmfcnet_hip.so")      # (MFC_LIB: another build of the same library, for A/B measurements)
 
 F32, BF16, F16 = 0, 1, 2
 

@@ -807,7 +807,7 @@ def test_bucketed_backward_hook_covers_the_arena(mfc):
         # unpack runs there; the chain itself no longer waits for it) reads the bucket
         seen.append((lo, hi))
         side.wait_stream(torch.cuda.current_stream())
-        assert L.lib.mfc_wait_detached(C.c_void_p(side.cuda_stream)) == 0
+        assert L.lib.mfc_wait_detached_ctx(m._ctx.handle, C.c_void_p(side.cuda_stream)) == 0          # (the model's own interpreter context)
         with torch.cuda.stream(side):
             snaps.append((lo, hi, m._G[lo:hi].detach().clone()))
 
