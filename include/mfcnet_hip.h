@@ -141,6 +141,13 @@ typedef struct {
     const void* in_fin;
 } mfc_conv_desc;
 #define MFC_CONV_WANT_FA 1
+/* flags bit 1 (round 4): this launch is the data gradient of a 3x3 / stride-2 / pad-1 convolution over ALL FOUR output parity classes at once
+ * (instead of four launches): TA = TB = 2, dh0 = dw0 = 0, in_stride = 1, out_sh = out_sw = 2, out_oh = out_ow = 0, Hl = ceil(Hout / 2),
+ * Wl = ceil(Wout / 2).  Class c = 2 ph + pw computes, on the dy grid, the 2x2-tap problem of output pixels (2i + ph, 2j + pw) from ITS weight
+ * image: the packed image (mfc_conv2d_layout(d).bytes) holds the four class images one after the other, each packed by an mfc_pack_job with
+ * TA = TB = 2, kh_step = kw_step = -2 and (kh0, kw0) = (1 + ph, 1 + pw) -- taps that fall outside the filter are written as zeros.  The
+ * epilogue options (accumulate, acc_src, bn_y, out_stats) apply to every class. */
+#define MFC_CONV_S2_CLASSES 2
 int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream);
 /* The packed weight image a launch of `d` reads is laid out [TA/TAS][nchunks][Yblocks][nslots][NT16][granule]
  * (slot = (row-in-group, tap column, granule-in-chunk)): the weights of one (tap-row group, channel chunk, cout block) stage are one contiguous block that is DMA-copied

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
 
 // ------------------------------------------------------------------------------------------
 bool ring_eligible(const mfc_conv_desc* d) {
-    if (!g_conv_ring || !d || !mfc_is16(d->dtype)) return false;
+    if (!g_conv_ring || !d || !mfc_is16(d->dtype) || (d->flags & MFC_CONV_S2_CLASSES)) return false;
     if (d->TA != 3 || d->TB != 3 || d->dh0 != -1 || d->dw0 != -1 || d->in_stride != 1) return false;
     if (d->out_sh != 1 || d->out_sw != 1 || d->out_oh != 0 || d->out_ow != 0) return false;
     if (d->Hin != d->Hout || d->Win != d->Wout || d->Hl != d->Hout || d->Wl != d->Wout) return false;

@@ -305,7 +305,7 @@ int g_conv_gemm = 1;                 // big 1x1 convolutions through conv_gemm1x
 int g_conv_gemm_minc = 128;          // smallest Cin / Cout (channels) sent there; tuning: mfc_set_flag(24, n)
 
 bool gemm1x1_eligible(const mfc_conv_desc* d) {
-    if (!g_conv_gemm || !mfc_is16(d->dtype)) return false;
+    if (!g_conv_gemm || !mfc_is16(d->dtype) || (d->flags & MFC_CONV_S2_CLASSES)) return false;
     if (d->TA != 1 || d->TB != 1 || d->in_stride != 1 || d->dh0 != 0 || d->dw0 != 0) return false;
     if (d->out_sh != 1 || d->out_sw != 1 || d->out_oh != 0 || d->out_ow != 0) return false;
     if (d->Hl != d->Hout || d->Wl != d->Wout || d->Hin != d->Hout || d->Win != d->Wout) return false;

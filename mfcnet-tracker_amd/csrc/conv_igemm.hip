@@ -42,6 +42,8 @@ struct ConvK {
     int ybfast;                              // unit order: 1 = cout block fastest (the Yblocks units of a pixel tile run back to back on one workgroup: the re-reads of the tile hit L2 instead of HBM)
     int wres;                                // >0: single-stage launch whose Yblocks weight stages ALL stay in LDS (wres = Yblocks); the pixel tile is staged once for its Yblocks units
     int wt;                                  // write-through output stores (common.h: large outputs only)
+    int ncls;                                // 4: data gradient of a 3x3 / stride-2 convolution, all four output parity classes in this launch (MFC_CONV_S2_CLASSES); else 1
+    long cls_bytes;                          // bytes of one class's packed weight image
     int ablate;                              // tuning only: 1 skip weight DMA, 2 skip patch staging, 4 skip output stores, 8 skip MFMAs
     // data-gradient epilogue fusions (bf16 FA variants; include/mfcnet_hip.h): accumulate from another tensor; BatchNorm-backward statistics
     const char* acc_src; const char* bn_y; const float* bn_coef; const unsigned char* bn_bits; int bn_mode;
@@ -161,9 +163,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
     const bool p_xf = (p.in_coef != nullptr);
 
     // unit = (cout block yb [slowest], image n, tile row, tile column [fastest]); tracked incrementally (no divisions per stage)
-    struct UC { int yb, n, tyi, txi; };
+    // (cls = output parity class of a merged stride-2 data gradient, slowest: class c writes pixels (2i + (c >> 1), 2j + (c & 1)) from its own weight image)
+    struct UC { int yb, n, tyi, txi, cls; };
     auto uc_init = [&](int u) {
         UC r; int xt;
+        r.cls = 0;
+        if (p.ncls > 1) { const int per = p.ntiles * p.Yblocks; r.cls = u / per; u -= r.cls * per; }
         if (p.ybfast) { xt = u / p.Yblocks; r.yb = u - xt * p.Yblocks; }
         else { r.yb = u / p.ntiles; xt = u - r.yb * p.ntiles; }
         r.txi = xt % p.tilesX; xt /= p.tilesX; r.tyi = xt % p.tilesY; r.n = xt / p.tilesY;
@@ -173,10 +178,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
         if (p.ybfast) {
             if (++r.yb < p.Yblocks) return r;
             r.yb = 0;
-            if (++r.txi == p.tilesX) { r.txi = 0; if (++r.tyi == p.tilesY) { r.tyi = 0; ++r.n; } }
+            if (++r.txi == p.tilesX) { r.txi = 0; if (++r.tyi == p.tilesY) { r.tyi = 0; if (++r.n == p.N && p.ncls > 1) { r.n = 0; ++r.cls; } } }
             return r;
         }
-        if (++r.txi == p.tilesX) { r.txi = 0; if (++r.tyi == p.tilesY) { r.tyi = 0; if (++r.n == p.N) { r.n = 0; ++r.yb; } } }
+        if (++r.txi == p.tilesX) { r.txi = 0; if (++r.tyi == p.tilesY) { r.tyi = 0; if (++r.n == p.N) { r.n = 0; if (++r.yb == p.Yblocks && p.ncls > 1) { r.yb = 0; ++r.cls; } } } }
         return r;
     };
     auto load_patch = [&](const UC& uc, int c) {
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
     // async global -> LDS copy of the packed weights of stage (a, c, cout block): the packed image is laid out
     // [TA][nchunks][Yblocks][nslots][NT16][16 B], i.e. one stage is ONE contiguous block = the LDS image
     auto dma_w = [&](const UC& uc, int c, int ag, char* wl) {
-        const char* src = p.wp + (size_t)((ag * p.nchunks + c) * p.Yblocks + uc.yb) * p.stage_bytes + lane * 16;
+        const char* src = p.wp + (size_t)uc.cls * p.cls_bytes + (size_t)((ag * p.nchunks + c) * p.Yblocks + uc.yb) * p.stage_bytes + lane * 16;
         // Issued as inline asm: through the builtin hipcc assumes the DMA's LDS write may alias every later ds_read and
         // drains it (s_waitcnt vmcnt(0)) before the compute loop, i.e. no overlap.  The buffers are disjoint by
         // construction (double buffer); completion is awaited explicitly (dma_wait) before the stage-end barrier.
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
     TR(1);
 
     if (p.ablate & 32) return;
-    const bool resident = (p.nchunks == 1 && p.nstg == 1 && p.Yblocks == 1) || p.wres;
+    const bool resident = (p.nchunks == 1 && p.nstg == 1 && p.Yblocks == 1 && p.ncls <= 1) || p.wres;
     int tl = 0, c = 0, a = 0;          // current stage coordinates (a = tap-row group)
     for (int g = 0; g < total; ++g) {
         int tl2 = tl, c2 = c, a2 = a + 1;
@@ -408,17 +413,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
         if (c == p.nchunks - 1 && a == p.nstg - 1 && !(p.ablate & 64)) {
             const int n = uc.n, i0 = uc.tyi * p.TH, j0 = uc.txi * p.TW, yb = uc.yb;
             const int n0 = yb * NT16;
+            // logical grid and output phase of this unit: the launch's, or its parity class's
+            const int c_ooh = p.ncls > 1 ? (uc.cls >> 1) : p.ooh, c_oow = p.ncls > 1 ? (uc.cls & 1) : p.oow;
+            const int c_Hl = p.ncls > 1 ? ((p.Hout - c_ooh + 1) >> 1) : p.Hl, c_Wl = p.ncls > 1 ? ((p.Wout - c_oow + 1) >> 1) : p.Wl;
             if constexpr (FA) {
                 // Variants with register slack: wave-uniform tile origin + the per-lane offsets of the prologue (no 64-bit
                 // vector address math per store).  bf16: the MFMA leaves a lane with 4 channels of cout tile nt; two cout tiles
                 // are transposed across the four 16-lane rows (v_permlane32_swap + v_permlane16_swap) so that every lane owns
                 // 8 CONTIGUOUS channels of its pixel -> one 16-byte store per tile pair, 64 contiguous bytes per pixel (the
                 // 8-byte stores to 32-byte half lines cost ~250 cycles of issue each: the memory pipeline works per line touched)
-                const size_t toff = ((((size_t)n * p.Hout + (i0 * p.osh + p.ooh)) * p.Wout + (j0 * p.osw + p.oow)) * p.Cout_p + n0) * sizeof(T);
+                const size_t toff = ((((size_t)n * p.Hout + (i0 * p.osh + c_ooh)) * p.Wout + (j0 * p.osw + c_oow)) * p.Cout_p + n0) * sizeof(T);
                 char* tbase = p.out + toff;
                 const char* abase = ((FUSE && p.acc_src) ? p.acc_src : (const char*)p.out) + toff;      // where the running sum of an accumulating launch lives
                 const bool bnm = FUSE && BF && p.bn_y != nullptr;                             // fused BatchNorm-backward statistics (wave-uniform)
-                const bool full = (i0 + p.TH <= p.Hl) && (j0 + p.TW <= p.Wl);
+                const bool full = (i0 + p.TH <= c_Hl) && (j0 + p.TW <= c_Wl);
                 constexpr int NP = BF ? NT / 2 : 0;              // cout tile pairs stored transposed
                 // Fused data-gradient epilogue: ALL global reads of the tile epilogue (running sum, pre-BN tensor, mask bits) are issued up
                 // front, so their latency is paid once per tile and not once per 16-pixel row (issued next to their use they cost
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                 if constexpr (FUSE && BF) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const bool vpx = pin[mt] && (full || ((i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl)));
+                        const bool vpx = pin[mt] && (full || ((i0 + pty[mt] < c_Hl) && (j0 + ptx[mt] < c_Wl)));
 #pragma unroll
                         for (int pr = 0; pr < NP; ++pr) {
                             const bool vc = (n0 + pr * 32 + (lane >> 4) * 8) < p.Cout_p;
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const bool vpx = pin[mt] && (full || ((i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl)));
+                    const bool vpx = pin[mt] && (full || ((i0 + pty[mt] < c_Hl) && (j0 + ptx[mt] < c_Wl)));
                     float v[NT][4];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
@@ -563,8 +571,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
             } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const bool valid = pin[mt] && (i0 + pty[mt] < p.Hl) && (j0 + ptx[mt] < p.Wl);
-                const int oi = (i0 + pty[mt]) * p.osh + p.ooh, oj = (j0 + ptx[mt]) * p.osw + p.oow;
+                const bool valid = pin[mt] && (i0 + pty[mt] < c_Hl) && (j0 + ptx[mt] < c_Wl);
+                const int oi = (i0 + pty[mt]) * p.osh + c_ooh, oj = (j0 + ptx[mt]) * p.osw + c_oow;
                 T* orow = (T*)(p.out + (((size_t)n * p.Hout + oi) * p.Wout + oj) * p.Cout_p * sizeof(T));
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
                 bool flush = (tl + 1 >= nun);
                 if (!flush) {
                     const UC un = uc_next(uc);
-                    flush = (un.yb != yb) || (un.n / p.ipg != n / p.ipg);
+                    flush = (un.yb != yb) || (un.n / p.ipg != n / p.ipg);        // (a class change of a merged stride-2 launch keeps (group, channel): no flush needed)
                 }
                 if (flush) stats_to_lds(n0, n / p.ipg, (u0 + tl + blockIdx.x) % MFC_R);
             }
@@ -692,6 +700,13 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     if (!mfc_dtype_ok(d->dtype)) return MFC_ERR_INVALID_ARG;
     const int E = mfc_is16(d->dtype) ? 8 : 4;
     if (d->Cin_p % 8 || d->Cout_p % 8 || d->Cin > d->Cin_p || d->Cout > d->Cout_p) return MFC_ERR_INVALID_ARG;
+    // MFC_CONV_S2_CLASSES: the data gradient of a 3x3 / stride-2 / pad-1 convolution as ONE launch over its four output parity classes (round 4: they
+    // used to be four launches of 9-26 us each for a few us of work -- 204 launches, 2.8 ms of a W32 step).  Every class is the same 2x2-tap
+    // problem on the dy grid (taps the class does not have are zero in its weight image): logical pixel (i, j) of class (ph, pw) -> tensor
+    // pixel (2i + ph, 2j + pw); classes differ only in their weight image (consecutive in wp) and in where they store.
+    const bool s2c = (d->flags & MFC_CONV_S2_CLASSES) != 0;
+    if (s2c && (d->TA != 2 || d->TB != 2 || d->dh0 != 0 || d->dw0 != 0 || d->in_stride != 1 || d->out_sh != 2 || d->out_sw != 2 || d->out_oh != 0 ||
+                d->out_ow != 0 || d->Hl != (d->Hout + 1) / 2 || d->Wl != (d->Wout + 1) / 2 || d->bias || d->TH > 0 || d->TW > 0)) return MFC_ERR_INVALID_ARG;
     if (d->N <= 0 || d->Hl <= 0 || d->Wl <= 0 || d->TA <= 0 || d->TB <= 0 || d->in_stride < 1) return MFC_ERR_INVALID_ARG;
     if ((d->Hl - 1) * d->out_sh + d->out_oh >= d->Hout || (d->Wl - 1) * d->out_sw + d->out_ow >= d->Wout) return MFC_ERR_INVALID_ARG;
     if (d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
@@ -736,7 +751,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
         }
         c.tilesY = ceil_div(d->Hl, c.TH); c.tilesX = ceil_div(d->Wl, c.TW);
         c.PH = (c.TH - 1) * c.s + c.TA; c.PW = (c.TW - 1) * c.s + c.TB;
-        const long units = (long)c.N * c.tilesY * c.tilesX * c.Yblocks;
+        const long units = (long)c.N * c.tilesY * c.tilesX * c.Yblocks * (s2c ? 4 : 1);
         // parallelism: a launch wants >= ~2 units per CU-slot (512 slots); fewer units -> idle CUs
         const double fill = units >= slots ? 1.0 : pow((double)units / (double)slots, g_conv_fill_pct / 100.0);
         for (int tas = c.TA; tas >= 1; tas = (tas == 1 ? 0 : 1)) {
@@ -756,7 +771,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
                 const size_t wbytes = ((size_t)t.stage_bytes + 1023) & ~(size_t)1023;
                 t.npieces = (int)(wbytes / 1024);
                 t.off_w0 = (int)((patch + 1023) & ~(size_t)1023);
-                const bool one_w = (t.nchunks == 1 && t.nstg == 1 && t.Yblocks == 1);      // resident weights: no second buffer
+                const bool one_w = (t.nchunks == 1 && t.nstg == 1 && t.Yblocks == 1 && !s2c);      // resident weights: no second buffer (classes of a merged stride-2 launch have their own weights)
                 t.off_w1 = t.off_w0 + (one_w ? 0 : (int)wbytes);
                 t.off_ktab = t.off_w1 + (int)wbytes;
                 t.off_red = t.off_ktab + ((t.nslots * 4 + 15) & ~15);
@@ -784,7 +799,9 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     k = bk; MT = bMT; PM = bPM; lds = blds; NWsel = bNW;
     if (!ok) return MFC_ERR_UNSUPPORTED;
     k.ntiles = k.N * k.tilesY * k.tilesX;
-    k.nunits = k.ntiles * k.Yblocks;
+    k.ncls = s2c ? 4 : 1;
+    k.cls_bytes = (long)k.nstg * k.nchunks * k.Yblocks * k.stage_bytes;
+    k.nunits = k.ntiles * k.Yblocks * k.ncls;
     k.ablate = g_conv_ablate;
     k.wt = 0;          // (measured: this family is SLOWER with write-through stores at every threshold -- 15.78 -> 16.05 ms per serial step; common.h)
     {   // cout-block-fastest order when the Yblocks passes over the input would otherwise each stream it from HBM again
@@ -792,7 +809,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
         k.ybfast = g_conv_ybfast >= 0 ? (g_conv_ybfast && k.Yblocks > 1) : (k.Yblocks > 1 && in_bytes * (k.Yblocks - 1) > 128e6);
     }
     k.wres = 0;
-    if (g_conv_wres && k.nchunks == 1 && k.nstg == 1 && k.Yblocks > 1) {
+    if (g_conv_wres && k.nchunks == 1 && k.nstg == 1 && k.Yblocks > 1 && !s2c) {
         // every cout block's weights fit next to the patch: keep them all in LDS and stage each pixel tile once
         const int wb = k.npieces * 1024;
         const int ktab = k.off_w0 + k.Yblocks * wb, redo = ktab + (k.off_red - k.off_ktab), dum = redo + (k.off_dummy - k.off_red);
@@ -833,8 +850,10 @@ static int conv_launch(const ConvK& k, size_t lds, int grid, hipStream_t st) {
     if (g_mfc_prof_on == 1) {
         MFC_PROF_NAME(pname, "conv_igemm_kernel<%s, %d, %d, %d, %d, %s>", mfc_tname<T>(), NT, MT, PMAX, NW, FUSE ? "true" : "false");
         const double E = sizeof(T) == 2 ? 8.0 : 4.0;
-        const double flops = 2.0 * k.N * k.Hl * k.Wl * (double)k.Cout * k.TA * k.TB * (k.Cin_g * E);
-        const double bytes = ((double)k.N * k.Hin * k.Win * k.Cin_g * 16.0) / (k.osh * k.osw) + (double)k.N * k.Hl * k.Wl * k.Cout_p * sizeof(T);
+        // (a merged stride-2 data gradient computes 4 classes x 4 taps, of which 9 are real: the algorithmic work is the 9)
+        const double flops = 2.0 * k.N * k.Hl * k.Wl * (double)k.Cout * (k.ncls > 1 ? 9.0 : (double)(k.TA * k.TB)) * (k.Cin_g * E);
+        const double bytes = k.ncls > 1 ? ((double)k.N * k.Hin * k.Win * k.Cin_g * 16.0 + (double)k.N * k.Hout * k.Wout * k.Cout_p * sizeof(T))
+                                        : (((double)k.N * k.Hin * k.Win * k.Cin_g * 16.0) / (k.osh * k.osw) + (double)k.N * k.Hl * k.Wl * k.Cout_p * sizeof(T));
         mfc_prof_before(st, pname, flops, bytes);
     }
     hipLaunchKernelGGL((conv_igemm_kernel<T, NT, MT, PMAX, NW, FUSE>), dim3(grid), dim3(NW * 64), lds, st, k);
@@ -865,7 +884,7 @@ extern "C" int mfc_conv2d_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
     if (rc < 0 || !out) return rc < 0 ? rc : MFC_ERR_INVALID_ARG;
     out->KG = k.KG; out->nchunks = k.nchunks; out->NT16 = NT * 16; out->Yblocks = k.Yblocks; out->nslots = k.nslots;
     out->TA = k.TA; out->TB = k.TB; out->lds_bytes = (int32_t)lds; out->TAS = k.TAS;
-    out->bytes = (int64_t)k.nstg * k.nchunks * k.Yblocks * k.stage_bytes;
+    out->bytes = (int64_t)k.nstg * k.nchunks * k.Yblocks * k.stage_bytes * k.ncls;        // (a merged stride-2 data gradient: four class images, one after the other)
     out->MT = MT; out->TH = k.TH; out->TW = k.TW; out->grid = grid; out->per_block = k.per_block; out->NW = NW;
     out->fa = conv_variant_fa(d->dtype, NT, MT, PM, NW) ? 1 : 0;
     return MFC_OK;

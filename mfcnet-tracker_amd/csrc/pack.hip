@@ -24,10 +24,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const mfc_pack_job* j
     const int slot = (int)(r % j.nslots); r /= j.nslots;
     const int yb = (int)(r % j.Yblocks); r /= j.Yblocks;
     const int c = (int)(r % j.nchunks); const int ag = (int)(r / j.nchunks);
-    const bool sv = slot < j.TAS * j.TB * j.KG;
+    bool sv = slot < j.TAS * j.TB * j.KG;
     const int al = slot / (j.TB * j.KG); const int rs = slot - al * j.TB * j.KG;
     const int b = rs / j.KG, gi = rs - b * j.KG;
     const int kh = j.kh0 + (ag * j.TAS + al) * j.kh_step, kw = j.kw0 + b * j.kw_step;
+    sv = sv && kh >= 0 && kh < j.KH && kw >= 0 && kw < j.KW;      // (a tap outside the filter: zero -- the parity classes of a merged stride-2 data gradient are padded to 2x2 taps)
     const int n = yb * j.NT16 + nn;
     const float* src = (const float*)j.src;
     float f[E];

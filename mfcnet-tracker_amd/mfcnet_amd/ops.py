@@ -66,10 +66,23 @@ def s2_class(k, pad, ph):
 
 def pack_weight(w: torch.Tensor, desc: L.ConvDesc, mode="fwd", cls=(0, 0)) -> torch.Tensor:
     """Pack fp32 [Cout,Cin,k,k] weights (cuda) into the image the launch `desc` reads.
-    mode: 'fwd' | 'dgrad' (stride 1) | 'dgrad_s2' (output parity class cls)."""
+    mode: 'fwd' | 'dgrad' (stride 1) | 'dgrad_s2' (output parity class cls) | 'dgrad_s2_all' (MFC_CONV_S2_CLASSES: the four class images of a
+    3x3 / stride-2 data gradient, one after the other; taps outside the filter are zero)."""
     Cout, Cin, k, _ = w.shape
     pad = k // 2
     lay = L.conv_layout(desc)
+    if mode == "dgrad_s2_all":
+        assert k == 3 and (lay.TA, lay.TB) == (2, 2) and lay.bytes % 4 == 0
+        out = torch.empty(lay.bytes, dtype=torch.uint8, device="cuda")
+        jobs = []
+        for ph in range(2):
+            for pw in range(2):
+                j = dict(TA=2, TB=2, kh0=1 + ph, kh_step=-2, kw0=1 + pw, kw_step=-2, mode=1)
+                j.update(L.pack_job_fields(lay))
+                j.update(src=w.data_ptr(), dst=out.data_ptr() + (2 * ph + pw) * (lay.bytes // 4), Cout=Cout, Cin=Cin, KH=k, KW=k)
+                jobs.append(j)
+        _run_jobs(jobs, L.PackJob, L.lib.mfc_pack_weights, desc.dtype)
+        return out
     if mode == "fwd":
         j = dict(TA=k, TB=k, kh0=0, kh_step=1, kw0=0, kw_step=1, mode=0)
     elif mode == "dgrad":
@@ -103,8 +116,9 @@ def conv2d(x, w, k, stride=1, bias=None, in_coef=None, in_relu=False, ipg=None, 
     return out
 
 
-def conv2d_dgrad(dy, w, k, stride, in_hw, accumulate_into=None):
-    """Data gradient: dy NHWC [N,Ho,Wo,Cop] -> dx NHWC [N,H,W,Cip]."""
+def conv2d_dgrad(dy, w, k, stride, in_hw, accumulate_into=None, merged_s2=False):
+    """Data gradient: dy NHWC [N,Ho,Wo,Cop] -> dx NHWC [N,H,W,Cip].  merged_s2: a 3x3 / stride-2 gradient as ONE launch over its four output
+    parity classes (MFC_CONV_S2_CLASSES) instead of four launches."""
     N, Ho, Wo, Cop = dy.shape
     Cout, Cin = w.shape[0], w.shape[1]
     H, W = in_hw
@@ -117,6 +131,14 @@ def conv2d_dgrad(dy, w, k, stride, in_hw, accumulate_into=None):
         wp = pack_weight(w, d, "dgrad")
         d.wp = wp.data_ptr()
         L.call(L.lib.mfc_conv2d_fwd, d)
+    elif merged_s2:
+        d = L.ConvDesc(dy.data_ptr(), 0, dx.data_ptr(), 0, 0, 0, dt_of(dy), N, Ho, Wo, Cop, Cout, H, W, dx.shape[3], Cin, (H + 1) // 2, (W + 1) // 2,
+                       2, 2, 0, 0, 1, 2, 2, 0, 0, 0, N, acc, 0, 0)
+        d.flags = L.CONV_S2_CLASSES
+        wp = pack_weight(w, d, "dgrad_s2_all")
+        d.wp = wp.data_ptr()
+        L.call(L.lib.mfc_conv2d_fwd, d)
+        torch.cuda.synchronize()
     else:
         keep = []
         for ph in range(2):

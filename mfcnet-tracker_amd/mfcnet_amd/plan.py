@@ -178,6 +178,8 @@ class Plan:
         # sums -> fp64 sqrt -> coefficient write -> read back) costs a convolution +2..4 us and a combine +5..9 us against the 3.7 us
         # launch it removes: serial forward 12.3 -> 12.7 ms, step and b=1 step unchanged.
         self.fold_fin = bool(getattr(model, "fold_bn_finalize", False))
+        # data gradient of a 3x3 / stride-2 convolution as ONE launch over its four output parity classes instead of four launches (round 4)
+        self.merge_s2 = bool(getattr(model, "merge_s2_dgrad", True))
         self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc", "fin")}
         self.dry = dry
         self._build()                       # sizing pass
@@ -288,6 +290,22 @@ class Plan:
                                    k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, y.ipg, 0, 0, 0)
                     d.flags = L.CONV_WANT_FA if self.fuse_bnred else 0      # (before packing: the weight image follows the geometry)
                     self._pack(d, src, cout, cin, k, TA=k, TB=k, kh0=k - 1, kh_step=-1, kw0=k - 1, kw_step=-1, mode=1)
+                    ci.dgrad.append(d)
+                elif stride == 2 and k == 3 and pad == 1 and self.merge_s2:
+                    # ONE launch over the four output parity classes (MFC_CONV_S2_CLASSES, include/mfcnet_hip.h): every class is the same
+                    # 2x2-tap problem on the dy grid with its own weight image (taps it does not have are packed as zeros)
+                    d = L.ConvDesc(16, 0, 16, 0, 0, 0, self.dtype, y.N, y.H, y.W, y.Cp, cout, xt.H, xt.W, xt.Cp, xt.C, (xt.H + 1) // 2, (xt.W + 1) // 2,
+                                   2, 2, 0, 0, 1, 2, 2, 0, 0, 0, y.ipg, 0, 0, 0)
+                    d.flags = L.CONV_S2_CLASSES | (L.CONV_WANT_FA if self.fuse_bnred else 0)
+                    lay = L.conv_layout(d)
+                    dst = self._alloc("act", lay.bytes)
+                    for ph in range(2):
+                        for pw in range(2):
+                            job = dict(src=src, dst=dst + (2 * ph + pw) * (lay.bytes // 4), Cout=cout, Cin=cin, KH=k, KW=k, TA=2, TB=2,
+                                       kh0=1 + ph, kh_step=-2, kw0=1 + pw, kw_step=-2, mode=1)
+                            job.update(L.pack_job_fields(lay))
+                            self.pack_jobs.append(job)
+                    d.wp = dst
                     ci.dgrad.append(d)
                 else:
                     assert stride == 2

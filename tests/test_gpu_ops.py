@@ -144,6 +144,32 @@ def test_conv_dgrad(M, case, dtype):
     assert relerr(ops.to_nchw(dx2, Cin).cpu(), 2 * x.grad) < 2 * TOL[dtype]
 
 
+S2_MERGED_CASES = [(2, 64, 64, 24, 32), (1, 48, 96, 23, 30), (2, 192, 384, 30, 40), (3, 32, 128, 15, 21), (2, 256, 96, 16, 24), (1, 3, 64, 33, 47)]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", S2_MERGED_CASES)
+def test_stride2_dgrad_as_one_launch_over_the_parity_classes(M, case, dtype):
+    """MFC_CONV_S2_CLASSES (round 4): the data gradient of a 3x3 / stride-2 convolution (fuse-layer down-sampling chains hrnet.py:211-230,
+    transitions :361-386, the stem :426-431) as ONE launch whose units are (parity class, cout block, tile) with per-class weight images
+    (2x2 taps, the missing ones zero) -- against autograd's data gradient, odd sizes included, and with the accumulate option."""
+    _, L, ops = M
+    N, Cin, Cout, H, W = case
+    x = rnd(dtype, N, Cin, H, W, seed=6).requires_grad_(True)
+    w = rnd(dtype, Cout, Cin, 3, 3, seed=7, scale=1.0 / np.sqrt(Cin * 9))
+    y = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = rnd(dtype, *y.shape, seed=8)
+    y.backward(dy)
+    dx = ops.conv2d_dgrad(ops.to_nhwc(dy, dtype), w.cuda(), 3, 2, (H, W), merged_s2=True)
+    assert relerr(ops.to_nchw(dx, Cin).cpu(), x.grad) < TOL[dtype]
+    if dx.shape[3] > Cin:
+        assert float(dx[..., Cin:].float().abs().max()) == 0.0
+    dx4 = ops.conv2d_dgrad(ops.to_nhwc(dy, dtype), w.cuda(), 3, 2, (H, W))                    # the four-launch form
+    assert relerr(dx.float(), dx4.float()) < TOL[dtype]
+    dx2 = ops.conv2d_dgrad(ops.to_nhwc(dy, dtype), w.cuda(), 3, 2, (H, W), accumulate_into=dx.clone(), merged_s2=True)
+    assert relerr(ops.to_nchw(dx2, Cin).cpu(), 2 * x.grad) < 2 * TOL[dtype]
+
+
 FUSED_DG_CASES = [  # N, G, Cin, Cout, k, s, H, W, mask mode, accumulate from another tensor
     (6, 3, 32, 32, 3, 1, 24, 40, 2, False), (6, 3, 32, 32, 3, 1, 24, 40, 3, True), (4, 2, 64, 64, 3, 1, 17, 21, 3, True),
     (4, 2, 64, 64, 3, 1, 17, 21, 0, False), (6, 3, 64, 128, 3, 2, 30, 40, 2, False), (3, 3, 128, 128, 3, 1, 15, 20, 3, True),

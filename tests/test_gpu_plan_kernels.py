@@ -159,7 +159,7 @@ def run_node(ci, L, ops, seed):
             q.acc_src = srcd.data_ptr() if from_src else 0
             if fused:
                 q.bn_y, q.bn_coef, q.out_stats, q.bn_bits = yd2.data_ptr(), cf2d.data_ptr(), bst.data_ptr(), bits.data_ptr() if mode == 3 else 0
-            mode_s, cls = ("dgrad", (0, 0)) if s == 1 else ("dgrad_s2", (q.out_oh, q.out_ow))
+            mode_s, cls = ("dgrad", (0, 0)) if s == 1 else (("dgrad_s2_all", (0, 0)) if (q.flags & L.CONV_S2_CLASSES) else ("dgrad_s2", (q.out_oh, q.out_ow)))
             wq = ops.pack_weight(w.cuda(), q, mode_s, cls)
             keep.append(wq)
             q.wp = wq.data_ptr()
