@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--no-fp16-line", action="store_true", help="(accepted for old scripts: the fp16 side line is off unless --fp16-line)")
     ap.add_argument("--no-fp32-parity", action="store_true", help="skip the `fp32_parity` side object (throughput of the fp32 parity mode + max |logits - oracle| "
                     "on one clip; needs the CPU baseline leg, which evaluates the oracle's side of it)")
+    ap.add_argument("--sharded-adam", action="store_true", help="N > 1: reduce-scatter of the gradient arena + Adam on the rank's shard + all-gather of the "
+                    "parameters (dist.ShardedStep) instead of the bucketed all-reduce overlapped with the backward + replicated Adam")
     ap.add_argument("--weights", default="hash", choices=["hash", "init"], help="hash = key-hash generator of SURVEY.md 8(c)/(d) (the weights of the golden "
                     "fixtures; default), init = torch's default initialisation from a fixed seed")
     ap.add_argument("--serial", action="store_true", help="one stream: no branch lanes / detached weight-gradient streams (for kernel profiles)")
@@ -333,7 +335,11 @@ def main():
     frames, mask, depth, flow = synth(B, T, H, W, nc, 42 + 2000 + rank, device, args.depth, args.optflow)
 
     # (MFC_FORCE_BUCKETS: run the segmented backward + bucket hook on one GPU too, to measure what the segmentation costs)
-    reducer = GradBucketReducer(model, average=False) if (world > 1 or args.force_dist or os.environ.get("MFC_FORCE_BUCKETS")) else None
+    reducer = GradBucketReducer(model, average=False) if ((world > 1 or args.force_dist or os.environ.get("MFC_FORCE_BUCKETS")) and not args.sharded_adam) else None
+    sharded = None
+    if args.sharded_adam and (world > 1 or args.force_dist):
+        from mfcnet_amd.dist import ShardedStep
+        sharded = ShardedStep(model)
 
     def fwd():
         return model(frames[0]) if args.single else model(frames, optflow=flow, depth=depth)
@@ -350,7 +356,10 @@ def main():
         (loss * lscale if lscale != 1.0 else loss).backward()       # (per-bucket all-reduces start inside, next to the backward kernels)
         if reducer is not None:
             reducer.finish()                                        # ... so the ranks' gradients add up (SUM: global-batch loss)
-        opt.step(grad_scale=1.0 / lscale)
+        if sharded is not None:
+            sharded.step(opt, grad_scale=1.0 / lscale)              # reduce-scatter -> Adam on this rank's shard -> all-gather
+        else:
+            opt.step(grad_scale=1.0 / lscale)
         return loss
 
     def sync():
@@ -555,7 +564,8 @@ def main():
                           "frames_per_clip": T, "parallelism": f"dp{world}", "ranks": world,
                           "backend": (args.backend if world > 1 else None), "launcher": os.environ.get("MFC_BENCH_LAUNCHER", "external" if external else "bench.py"),
                           "devices": [f"{h}:cuda{d}" for h, d in devs], "rccl_version": rccl_version(torch) if dist is not None and args.backend == "nccl" else None,
-                          "streams": "serial" if args.serial else "branch lanes + detached wgrad", "final_loss": round(final_loss, 5)},
+                          "streams": "serial" if args.serial else "branch lanes + detached wgrad",
+                          "exchange": (None if world == 1 and not args.force_dist else ("reduce-scatter + sharded Adam + all-gather" if args.sharded_adam else "bucketed all-reduce overlapped with the backward")), "final_loss": round(final_loss, 5)},
                "roofline": roof, "roofline_top": roof_top, "roofline_conv": roof_conv}
         if fp16_side is not None:
             out["fp16_storage"] = fp16_side
