@@ -103,6 +103,23 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert d["config"]["launcher"] == "external"
 
 
+def test_bench_two_ranks_sharded_adam_exchange():
+    """`--sharded-adam`: reduce-scatter of the gradient arena, Adam on the rank's shard, all-gather of the parameters (dist.ShardedStep) -- the same
+    step as the all-reduce exchange (two ranks: the same bits), so the final loss of the two runs agrees to the bf16 noise of four steps."""
+    _need_gpu()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    outs = []
+    for extra in ([], ["--sharded-adam"]):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-prof"] + extra + SMALL
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+        outs.append(_json_line(r.stdout))
+    a, b = outs
+    assert b["config"]["exchange"].startswith("reduce-scatter") and a["config"]["exchange"].startswith("bucketed all-reduce")
+    assert b["n_gpus"] == 2 and abs(a["config"]["final_loss"] - b["config"]["final_loss"]) < 1e-3, (a["config"]["final_loss"], b["config"]["final_loss"])
+
+
 def test_bench_gpus_flag_starts_the_ranks_itself():
     """`python bench.py --gpus 2` (the driver's form, no torchrun): the parent starts two ranks before touching the GPU and relays
     rank 0's line, which must report two ranks; a launcher whose world size disagrees with --gpus is refused."""
