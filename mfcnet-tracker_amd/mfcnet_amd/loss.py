@@ -18,6 +18,25 @@ from . import _lib as L
 DEFAULT_CLASS_WEIGHTS = (1.0, 1000.0, 1000.0, 1000.0, 1000.0)
 
 
+_CW_CACHE = {}
+
+
+def _class_weights(class_weights, device):
+    """the class-weight vector on the device, uploaded ONCE per (values, device): a host-to-device copy from pageable memory makes the host wait
+    for everything already enqueued on the stream (HIP stages it through the host), i.e. a hidden synchronisation between the forward and the
+    backward of every step -- the GPU then idles while Python enqueues the loss and the first backward records (1.5 ms in the event timeline of
+    round 4, `profiles/r04_timeline.txt`)."""
+    if torch.is_tensor(class_weights):
+        if class_weights.device == device and class_weights.dtype == torch.float32:
+            return class_weights
+        class_weights = tuple(float(x) for x in class_weights.detach().cpu().tolist())
+    key = (tuple(float(x) for x in class_weights), str(device))
+    t = _CW_CACHE.get(key)
+    if t is None:
+        t = _CW_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return t
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, class_w, w_nll, w_jac, group):
@@ -59,7 +78,7 @@ def mfc_loss(logits, target, class_weights=DEFAULT_CLASS_WEIGHTS, w_nll=0.7, w_j
     `check_labels=True` reads that counter back (one host sync) and raises IndexError like the reference would."""
     if not logits.is_cuda:
         raise L.MfcError("mfc_loss runs on the GPU only")
-    cw = torch.as_tensor(class_weights, dtype=torch.float32, device=logits.device)
+    cw = _class_weights(class_weights, logits.device)
     if target.dtype != torch.int64:
         target = target.long()
     g = None
