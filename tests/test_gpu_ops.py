@@ -173,17 +173,23 @@ def test_stride2_dgrad_as_one_launch_over_the_parity_classes(M, case, dtype):
 FUSED_DG_CASES = [  # N, G, Cin, Cout, k, s, H, W, mask mode, accumulate from another tensor
     (6, 3, 32, 32, 3, 1, 24, 40, 2, False), (6, 3, 32, 32, 3, 1, 24, 40, 3, True), (4, 2, 64, 64, 3, 1, 17, 21, 3, True),
     (4, 2, 64, 64, 3, 1, 17, 21, 0, False), (6, 3, 64, 128, 3, 2, 30, 40, 2, False), (3, 3, 128, 128, 3, 1, 15, 20, 3, True),
-    (6, 3, 64, 32, 1, 1, 20, 28, 2, False), (3, 1, 32, 64, 3, 2, 23, 30, 2, True)]
+    (6, 3, 64, 32, 1, 1, 20, 28, 2, False), (3, 1, 32, 64, 3, 2, 23, 30, 2, True),
+    # HRNet-W48's channel counts: 3- / 6-tile cout blocks, fused through the non-transposed epilogue (round 4)
+    (6, 3, 48, 48, 3, 1, 24, 40, 3, True), (4, 2, 96, 96, 3, 1, 17, 21, 2, False), (3, 3, 192, 192, 3, 1, 15, 20, 3, True),
+    (3, 1, 384, 384, 3, 1, 8, 12, 0, False), (6, 3, 48, 96, 3, 2, 30, 40, 2, False), (2, 2, 96, 192, 3, 2, 15, 21, 3, True)]
 
 
+@pytest.mark.parametrize("merged", [False, True], ids=["", "s2-one-launch"])
 @pytest.mark.parametrize("dt16", H16, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", FUSED_DG_CASES)
-def test_dgrad_fused_bn_backward_reduce(dt16, M, case):
+def test_dgrad_fused_bn_backward_reduce(dt16, M, case, merged):
     """mfc_conv_desc.bn_y / acc_src: a data-gradient launch that masks its result, accumulates the BatchNorm-backward statistics
     (sum g*m, sum g*m*yhat per group and channel) in its epilogue and reads its running sum from another tensor -- against autograd's
     data gradient with the mask / the sums applied on the CPU (the work mfc_bnbwd_reduce otherwise does in a second sweep)."""
     _, L, ops = M
     N, G, Cin, Cout, k, s, H, W, mode, acc = case
+    if merged and s != 2:
+        pytest.skip("merged form exists for stride-2 data gradients only")
     ipg = N // G
     x = rnd(dt16, N, Cin, H, W, seed=51).requires_grad_(True)
     w = rnd(dt16, Cout, Cin, k, k, seed=52, scale=1.0 / np.sqrt(Cin * k * k))
@@ -217,9 +223,14 @@ def test_dgrad_fused_bn_backward_reduce(dt16, M, case):
     coef_d = coef.cuda()
     Ho, Wo, pad = yo.shape[2], yo.shape[3], k // 2
     keep, launched = [], 0
-    classes = [(0, 0)] if s == 1 else [(a, b) for a in range(2) for b in range(2)]
+    classes = [(0, 0)] if (s == 1 or merged) else [(a, b) for a in range(2) for b in range(2)]
     for (ph, pw) in classes:
-        if s == 1:
+        if merged:       # MFC_CONV_S2_CLASSES: the four parity classes in one launch
+            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, (H + 1) // 2, (W + 1) // 2,
+                           2, 2, 0, 0, 1, 2, 2, 0, 0, 0, ipg, 1 if acc else 0, 0, 0)
+            d.flags = L.CONV_S2_CLASSES
+            mode_s, cls = "dgrad_s2_all", (0, 0)
+        elif s == 1:
             d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, H, W,
                            k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, ipg, 1 if acc else 0, 0, 0)
             mode_s, cls = "dgrad", (0, 0)
@@ -230,7 +241,7 @@ def test_dgrad_fused_bn_backward_reduce(dt16, M, case):
             d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, Hl, Wl,
                            ta, tb, dh0, dw0, 1, 2, 2, ph, pw, 0, ipg, 1 if acc else 0, 0, 0)
             mode_s, cls = "dgrad_s2", (ph, pw)
-        d.flags = L.CONV_WANT_FA
+        d.flags |= L.CONV_WANT_FA
         if L.conv_layout(d).fa != 1:
             pytest.skip("no fusable geometry for this shape")
         d.acc_src = srcd.data_ptr() if acc else 0
