@@ -43,7 +43,8 @@ extern "C" {
  *  52  ring kernel: workgroups per launch (0 = 256 x switch 33; probes of partitioned grids, tools/probe_group.py)
  *  53  descriptor hardening (0): 1 = every non-null pointer of a convolution / weight-gradient / combine / BatchNorm-backward / mask-add descriptor is checked with
  *      hipPointerGetAttributes before the launch (MFC_ERR_INVALID_ARG for host or unmapped addresses instead of a GPU fault); the -m gpu tests run with it on
- *  54  write-through (sc1) 16-byte output stores from this many MB of output per launch (12; 0 = plain stores everywhere): mfcnet-tracker_amd/csrc/common.h, mfc_st16 */
+ *  54  write-through (sc1) 16-byte output stores from this many MB of output per launch (12; 0 = plain stores everywhere): mfcnet-tracker_amd/csrc/common.h, mfc_st16
+ *  55  conv: score weight (%) of the 8-wave geometries for launches that want the fused data-gradient epilogue (0: 4-wave forms; -1 = switch 19) */
 int mfc_set_flag(int id, int value);
 #ifdef __cplusplus
 }

@@ -677,6 +677,9 @@ int mfc_conv_set_grid(int v) { g_conv_grid = v > 0 ? v : 512; return 0; }
 
 static int g_conv_nw8 = 90;           // 8-wave (one workgroup per CU) geometries: score weight in % (0 = never; 90 sends ties to the 4-wave form); tuning: mfc_set_flag(19, pct)
 int mfc_conv_set_nw8(int v) { g_conv_nw8 = v; return 0; }
+int g_conv_nw8_fused = 0;             // the same weight for launches that ask for the fused data-gradient epilogue (MFC_CONV_WANT_FA); -1 = g_conv_nw8.  0: those launches
+                                      // use 4-wave geometries -- alone they are slower (conv_igemm 14.6 -> 15.5 ms per serial step) but two workgroups per CU hide each
+                                      // other's exposed epilogue reads and share the chip better with the lanes: step 36.78 -> 36.60 ms (twice); mfc_set_flag(55, pct)
 
 static bool conv_variant_fa(int dtype, int NT, int MT, int PM, int NW);
 
@@ -735,7 +738,8 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     double best_score = -1; ConvK bk = k; int bMT = 2, bPM = 0, bNW = 4; size_t blds = 0;
     for (int nwi = 0; nwi < 2; ++nwi) {
     const int nw = nwi == 0 ? 4 : 8;
-    if (nw == 8 && (g_conv_nw8 <= 0 || E != 8)) continue;
+    const int nw8w = (want_fa && g_conv_nw8_fused >= 0) ? g_conv_nw8_fused : g_conv_nw8;
+    if (nw == 8 && (nw8w <= 0 || E != 8)) continue;
     const int slots = nw == 8 ? g_conv_grid / 2 : g_conv_grid;          // resident workgroups on the chip
     for (int mi = 0; mi < 2; ++mi) {
         const int mt = mi == 0 ? 4 : 2;
@@ -788,7 +792,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
                 if (l > lds_cap || pm > pm_max || t.nslots > 256) continue;
                 if (want_fa && !conv_variant_fa(d->dtype, NT, mt, pm, nw)) continue;
                 const double mf = (E == 8 ? t.nslots / 4 : t.nslots) * mt * NT;      // MFMAs per wave per stage
-                const double score = eff * fill * ((double)real / t.nslots) * (mf / (mf + 40.0)) * (mt == 4 ? 1.0 : 0.93) * (nw == 8 ? g_conv_nw8 / 100.0 : 1.0);
+                const double score = eff * fill * ((double)real / t.nslots) * (mf / (mf + 40.0)) * (mt == 4 ? 1.0 : 0.93) * (nw == 8 ? nw8w / 100.0 : 1.0);
                 if (score > best_score) { best_score = score; bk = t; bMT = mt; bPM = pm; blds = l; bNW = nw; }
             }
         }
