@@ -477,6 +477,9 @@ int mfc_set_lanes(int on) { g_lanes_on = on; return 0; }
 static int g_async_prio = 0;     // priority of the detached stream: 1 lowest, 0 default, -1 highest (read when the streams are created).  Measured:
                                  // either non-default priority costs 35 % of the step (526 -> 330 frames/s) -- keep 0; mfc_set_flag(16, v)
 int mfc_set_async_prio(int v) { g_async_prio = v; return 0; }
+static int g_lane4_fwd = 1;        // 1: in programs WITHOUT detached records (the forward pass) lane 4 -- the 15x20 branch of a four-branch module, otherwise folded onto the
+                                   // main stream -- runs on the detached stream's otherwise idle hardware queue: step 36.42 -> 35.73 ms, eval forward 9.74 -> 9.60 ms; mfc_set_flag(56, v)
+int mfc_set_lane4_fwd(int v) { g_lane4_fwd = v; return 0; }
 static int g_defer_join = 0;     // 1: a program does not join the detached stream at its end (the next program of the step will); mfc_set_flag(28, v)
 int mfc_set_defer_join(int v) { g_defer_join = v; return 0; }
 static int g_skip_kinds = 0;     // tuning only: bit k set -> records of kind k are skipped (what-if timing); mfc_set_flag(15, mask)
@@ -665,6 +668,12 @@ static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_jo
     // with lanes the whole program runs on the interpreter's own streams, ordered after / before the caller's stream by events
     hipStream_t mainst = (multi && !g_capturing && g_own_main) ? L->m : caller;
     if (mainst != caller) { (void)hipEventRecord(L->enter, caller); (void)hipStreamWaitEvent(mainst, L->enter, 0); }
+    // A program WITHOUT detached records (the forward pass: no weight gradients) leaves the detached stream -- the fourth hardware queue -- idle:
+    // the fourth branch of a module (lane 4, otherwise folded onto the main stream) may run there (mfc_set_flag(56, 1)).
+    bool has_async = false;
+    for (int i = 0; i < n && !has_async; ++i) has_async = (ops[i].lane & MFC_LANE_ASYNC) != 0;
+    const bool lane4_detached = multi && g_lane4_fwd && !has_async && !(L && L->pending) && !g_capturing;
+    auto side = [&](int l) -> hipStream_t { return (lane4_detached && l == 4) ? L->as[0] : L->s[l]; };
     bool in_par = false; unsigned used = 0;
     unsigned aused = (L && L->pending) ? 1u : 0u;     // detached work left over from a program that deferred its join: same stream, in order
     int anext = 0, aevn = 0;
@@ -677,11 +686,11 @@ static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_jo
             for (int l = 1; l <= MFC_MAX_LANES; ++l)
                 if (l == 1 || (used & (1u << l))) {
                     snprintf(names[l], sizeof(names[l]), "lane%d", l);
-                    mfc_prof_span(L->fork_t, l == 1 ? mainst : L->s[l], names[l], (double)sec_first);
+                    mfc_prof_span(L->fork_t, l == 1 ? mainst : side(l), names[l], (double)sec_first);
                 }
         }
         for (int l = 2; l <= MFC_MAX_LANES; ++l)
-            if (used & (1u << l)) { (void)hipEventRecord(L->join[l], L->s[l]); (void)hipStreamWaitEvent(mainst, L->join[l], 0); }
+            if (used & (1u << l)) { (void)hipEventRecord(L->join[l], side(l)); (void)hipStreamWaitEvent(mainst, L->join[l], 0); }
         in_par = false; used = 0;
     };
     auto join_async = [&]() {
@@ -697,7 +706,8 @@ static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_jo
     };
     for (int i = 0; i < n; ++i) {
         int lane = (multi && (g_lanes_on & 1)) ? (ops[i].lane & 0xff) : 0;
-        if (lane >= 1 && lane <= MFC_MAX_LANES && g_lane_map[lane]) lane = g_lane_map[lane] == -3 ? ((L && L->lane_b) ? 3 : 2) : g_lane_map[lane] == -4 ? ((L && L->lane_c) ? 4 : 1) : g_lane_map[lane];
+        if (lane == 4 && lane4_detached) lane = 4;
+        else if (lane >= 1 && lane <= MFC_MAX_LANES && g_lane_map[lane]) lane = g_lane_map[lane] == -3 ? ((L && L->lane_b) ? 3 : 2) : g_lane_map[lane] == -4 ? ((L && L->lane_c) ? 4 : 1) : g_lane_map[lane];
         else if (lane > g_lane_streams) lane = (lane - 1) % g_lane_streams + 1;      // fold the lanes onto the streams in use
         bool detached = multi && (g_lanes_on & 2) && (ops[i].lane & MFC_LANE_ASYNC);
         // a detached UNPACK sums the slices of weight gradients launched before it on the detached stream: in order only if that is ONE stream
@@ -706,8 +716,8 @@ static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_jo
         hipStream_t st = mainst;
         if (lane >= 2 && lane <= MFC_MAX_LANES) {
             if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; sec_first = i; if (g_mfc_prof_on == 2) L->fork_t = mfc_prof_mark(mainst); }
-            if (!(used & (1u << lane))) { (void)hipStreamWaitEvent(L->s[lane], L->fork, 0); used |= 1u << lane; }
-            st = L->s[lane];
+            if (!(used & (1u << lane))) { (void)hipStreamWaitEvent(side(lane), L->fork, 0); used |= 1u << lane; }
+            st = side(lane);
         } else if (lane == 1) {
             if (!in_par) { (void)hipEventRecord(L->fork, mainst); in_par = true; used = 0; sec_first = i; if (g_mfc_prof_on == 2) L->fork_t = mfc_prof_mark(mainst); }
         } else if (in_par) {
