@@ -2,10 +2,10 @@
 # Everything a round's profiles/ are condensed from, in one gpurun call (run from the repo root on the GPU box):
 #   rocprofv3 kernel stats + PMC passes for W32 and W48, the default bench lines, per-record profiles, what-if runs, the training soak
 set -e
-O=gpurun_out/round; rm -rf $O; mkdir -p $O
+O=gpurun_out/round${WIDTHS:+_w$WIDTHS}; rm -rf $O; mkdir -p $O
 TAG=${1:-r03_e}
 # (the rocprofv3 databases are ~60 MB per width and gpurun returns at most 64 MB: condense them here, keep only the small tables)
-for w in 32 48; do
+for w in ${WIDTHS:-32 48}; do
   bash tools/profile_round.sh $w > $O/profile_round_w$w.log 2>&1
   MFC_PROFILES_DIR=$O/profiles python tools/summarize_profile.py gpurun_out/prof_round ${TAG}_w$w 2 > $O/summarize_w$w.log 2>&1
   cp gpurun_out/prof_round/bench_*.log $O/ 2>/dev/null || true
@@ -13,6 +13,7 @@ for w in 32 48; do
   rm -rf gpurun_out/prof_round
 done
 cp $O/profiles/${TAG}_w*_pmc_traffic.json profiles/        # (bench.py looks the counter bytes up in the newest committed PMC table)
+[ -n "$ONLY_PROFILE" ] && exit 0
 python bench.py --steps 20 --warmup 5 > $O/bench_w32.json 2> $O/bench_w32.err
 python bench.py --width 48 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_w48.json 2> $O/bench_w48.err
 python bench.py --dtype fp16 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_w32_fp16.json 2> $O/bench_w32_fp16.err
