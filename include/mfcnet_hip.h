@@ -65,7 +65,9 @@ typedef enum {
     MFC_ERR_LAUNCH = -3
 } mfc_status;
 
+#ifndef MFC_STAT_REPLICAS      /* (an A/B build may define another count: make REPLICAS=4 -- the host side must then agree, MFC_STAT_REPLICAS in the environment) */
 #define MFC_STAT_REPLICAS 8    /* rows the per-channel sum atomics are spread over (8 / 16 / 32 measured on the full step: 39.3 / 39.5 / 39.7 ms -- every finalize reads all rows) */
+#endif
 /* Statistic sums (BatchNorm / GroupNorm forward sums, BatchNorm-backward sums) are fp64 cells added to with fp64 atomics: the fp32 partial
  * sums of the workgroups then add up to the same value whatever order the workgroups arrive in.  With fp32 cells the order noise of the
  * atomics (1e-7 relative) is amplified by var = E[x^2] - mean^2 on channels whose variance is small against their mean, and a bf16 training-mode
@@ -133,12 +135,6 @@ typedef struct {
     int32_t bn_mask_mode;
     int32_t flags;           /* bit 0 (MFC_CONV_WANT_FA): restrict the geometry search to launches that support the fusions above (fa = 1) when one
                               * exists -- set it BEFORE mfc_conv2d_layout / packing, so that the packed weight image matches the launch */
-    /* ---- optional: BatchNorm finalize of the PRODUCER folded into this launch (round 3).  in_fin = DEVICE pointer to the mfc_bnfin_desc
-     * whose `coef` is this launch's in_coef: every workgroup first turns the statistic sums into the coefficient block itself (identical
-     * values, written redundantly; the replica reads run under the launch's own first loads) and workgroup 0 updates the running
-     * statistics -- the one-block mfc_bn_finalize launch between producer and consumer (~3.7 us of dependent launch) disappears.
-     * Training-mode descriptors only; launches that cannot take an input transform return MFC_ERR_UNSUPPORTED. */
-    const void* in_fin;
 } mfc_conv_desc;
 #define MFC_CONV_WANT_FA 1
 /* flags bit 1 (round 4): this launch is the data gradient of a 3x3 / stride-2 / pad-1 convolution over ALL FOUR output parity classes at once
@@ -269,8 +265,6 @@ typedef struct {
     int32_t images_per_group;
     uint64_t maskbits;       /* optional (bf16): uint8 [N*H*W*out.Cp/8], bit e of byte (pixel*Cp + c)/8 = out[pixel][c + e] > 0 -- the
                               * ReLU mask the BatchNorm backward of the summed terms reads (mask_mode 3) instead of the whole tensor */
-    uint64_t fin;            /* optional: DEVICE pointer to the mfc_bnfin_desc (training mode, at most 128 channels) of ONE source's BatchNorm, folded into
-                              * this launch as in mfc_conv_desc.in_fin: its `coef` must be that source's view.coef */
 } mfc_combine_desc;
 int mfc_combine_fwd(const mfc_combine_desc* d, void* stream);
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "mfcnet_hip.h"
 
 typedef __bf16 bf16_t;
@@ -208,62 +209,3 @@ template <typename... P> static inline bool mfc_ptrs_ok(P... ptrs) {
     return mfc_ptrs_ok_impl(a, (int)(sizeof(a) / sizeof(a[0])));
 }
 #define MFC_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return MFC_ERR_LAUNCH; } while (0)
-
-// ---- BatchNorm finalize folded into a consumer launch (mfc_conv_desc.in_fin / mfc_combine_desc.fin): called by ALL threads of EVERY workgroup
-// before the first use of the coefficient block.  Same arithmetic, in the same order, as bn_finalize_body (elementwise.hip), so a folded
-// and a stand-alone finalize give the same bits.  Every workgroup writes the whole [G][4][Cp] block (identical values: a benign race) and
-// then reads its own writes back through its CU's L1 after the barrier (workgroup scope: one L1 per CU); `leader` (one workgroup of the
-// launch) also advances the running statistics, which nothing in a training-mode program reads.
-__device__ inline double mfc_replica_sum(const mfc_stat_t* base, size_t stride) {
-    double p[MFC_R];
-#pragma unroll
-    for (int r = 0; r < MFC_R; ++r) p[r] = base[(size_t)r * stride];
-    double s = 0.0;
-#pragma unroll
-    for (int r = 0; r < MFC_R; ++r) s += p[r];
-    return s;
-}
-__device__ __forceinline__ static void bn_fold_body(const mfc_bnfin_desc* fp, bool leader) {
-    const mfc_bnfin_desc d = *fp;
-    const int nt = (int)blockDim.x, tid = (int)threadIdx.x;
-    const size_t rstride = (size_t)d.G * 2 * d.Cp;
-    for (int i = tid; i < d.G * d.Cp; i += nt) {
-        const int g = i / d.Cp, c = i - g * d.Cp;
-        const bool real = c < d.C;
-        const float gamma = real ? d.gamma[c] : 0.f, beta = real ? d.beta[c] : 0.f;
-        float mean = 0.f, rstd = 0.f;
-        if (real) {
-            const double s = mfc_replica_sum(d.stats + ((size_t)g * 2 + 0) * d.Cp + c, rstride);
-            const double s2 = mfc_replica_sum(d.stats + ((size_t)g * 2 + 1) * d.Cp + c, rstride);
-            const double m = s / (double)d.count;
-            double v = s2 / (double)d.count - m * m;
-            if (v < 0.0) v = 0.0;
-            mean = (float)m; rstd = (float)(1.0 / sqrt(v + (double)d.eps));
-        }
-        float* cf = d.coef + (size_t)g * 4 * d.Cp + c;
-        const float scale = gamma * rstd;
-        cf[0] = scale; cf[d.Cp] = beta - mean * scale; cf[2 * d.Cp] = mean; cf[3 * d.Cp] = rstd;
-    }
-    if (leader) {
-        // running statistics, group after group (the reference calls base_model once per frame)
-        for (int c = tid; c < d.C; c += nt) {
-            float rm = d.running_mean[c], rv = d.running_var[c];
-            for (int g = 0; g < d.G; ++g) {
-                const double s = mfc_replica_sum(d.stats + ((size_t)g * 2 + 0) * d.Cp + c, rstride);
-                const double s2 = mfc_replica_sum(d.stats + ((size_t)g * 2 + 1) * d.Cp + c, rstride);
-                const double m = s / (double)d.count;
-                double v = s2 / (double)d.count - m * m;
-                if (v < 0.0) v = 0.0;
-                const double var = (double)(float)v;
-                const double unb = d.count > 1.f ? var * (double)d.count / ((double)d.count - 1.0) : var;
-                rm = (1.f - d.momentum) * rm + d.momentum * (float)m;
-                rv = (1.f - d.momentum) * rv + d.momentum * (float)unb;
-            }
-            d.running_mean[c] = rm; d.running_var[c] = rv;
-        }
-        if (d.num_batches_tracked && tid == 0) *d.num_batches_tracked += d.G;
-    }
-    __syncthreads();
-}
-// out-of-line form for the convolution kernels (called before anything is live, so that the fp64 arithmetic does not enter their register allocation)
-__device__ __noinline__ static void bn_fold_prologue(const mfc_bnfin_desc* fp, bool leader) { bn_fold_body(fp, leader); }

@@ -33,7 +33,6 @@ int g_ring_grid = 0;                      // > 0: workgroups per launch (tuning 
 struct RingK {
     const char* in; const char* wp; char* out;
     const float* in_coef; mfc_stat_t* out_stats;
-    const mfc_bnfin_desc* in_fin;                                // BatchNorm finalize of the producer folded into this launch (or null)
     const char* acc_src; const char* bn_y; const float* bn_coef; const unsigned char* bn_bits;
     int N, H, W, C;
     int in_relu, ipg, G, accumulate, bn_mode;
@@ -115,7 +114,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
     const int u0 = Lb * p.per_block;
     const int nun = min(p.per_block, p.ntiles - u0);
     if (nun <= 0) return;
-    if (p.in_fin) bn_fold_prologue(p.in_fin, Lb == 0);          // (before anything is live: an out-of-line call)
     const int H = p.H, W = p.W;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     if (p.stagger > 0) {
@@ -579,7 +577,7 @@ static void ring_geo(const mfc_conv_desc* d, RingK& k, size_t& lds, int& grid) {
 static int ring_setup(const mfc_conv_desc* d, RingK& k, size_t& lds, int& grid, int& MT) {
     if (!d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
     k.in = (const char*)d->in; k.wp = (const char*)d->wp; k.out = (char*)d->out;
-    k.in_coef = d->in_coef; k.out_stats = d->out_stats; k.in_fin = (const mfc_bnfin_desc*)d->in_fin;
+    k.in_coef = d->in_coef; k.out_stats = d->out_stats;
     k.acc_src = (const char*)d->acc_src; k.bn_y = (const char*)d->bn_y; k.bn_coef = d->bn_coef; k.bn_bits = (const unsigned char*)d->bn_bits;
     k.N = d->N; k.H = d->Hout; k.W = d->Wout; k.C = d->Cin;
     k.in_relu = d->in_relu; k.ipg = d->images_per_group; k.G = d->N / d->images_per_group; k.accumulate = d->accumulate; k.bn_mode = d->bn_mask_mode;

@@ -23,7 +23,6 @@
 struct GemmK {
     const char* in; const char* wp; char* out; const float* bias; mfc_stat_t* out_stats; const float* in_coef;
     int in_relu;
-    const mfc_bnfin_desc* in_fin;        // BatchNorm finalize of the producer folded into this launch (or null)
     int M, Cin_p, Cin_g, Cout_p, Cout;
     int nchunks, Yblocks, ntiles, tiles_per_block;
     int px_per_group, G, accumulate;
@@ -65,7 +64,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
     const int t0 = Lb * p.tiles_per_block;
     const int ntl = min(p.tiles_per_block, p.ntiles - t0);
     if (ntl <= 0) return;
-    if (p.in_fin) bn_fold_prologue(p.in_fin, Lb == 0);          // (before anything is live: an out-of-line call)
     // cout block fastest: the Yblocks units of a pixel tile run back to back and the re-reads of the tile hit L2.  The statistics of
     // up to G_MAXYB blocks are kept side by side in LDS across tiles; with more blocks the order flips (block slowest)
     const bool ybfast = (p.out_stats == nullptr) || p.Yblocks <= G_MAXYB;
@@ -343,7 +341,7 @@ int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st) {
     int grid = k.ntiles < 256 ? k.ntiles : 256;
     k.tiles_per_block = ceil_div(k.ntiles, grid);
     grid = ceil_div(k.ntiles, k.tiles_per_block);
-    k.in_coef = d->in_coef; k.in_relu = d->in_relu; k.in_fin = (const mfc_bnfin_desc*)d->in_fin;
+    k.in_coef = d->in_coef; k.in_relu = d->in_relu;
     const bool grouped = d->out_stats || d->in_coef;
     k.G = grouped ? d->N / d->images_per_group : 1;
     k.accumulate = d->accumulate;

@@ -26,7 +26,6 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 struct ConvK {
     const char* in; const char* wp; char* out;
     const float* bias; const float* in_coef; mfc_stat_t* out_stats;
-    const mfc_bnfin_desc* in_fin;        // BatchNorm finalize of the producer folded into this launch (or null)
     int N, Hin, Win, Cin_p, Cin_g;      // Cin_g: granules to reduce over
     int Hout, Wout, Cout_p, Cout;
     int Hl, Wl, TA, TB, dh0, dw0, s;
@@ -95,7 +94,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_igemm_kernel(Co
     const int nun = min(p.per_block, p.nunits - u0);
     if (nun <= 0) return;
     if (p.ablate & 16) return;
-    if (p.in_fin) bn_fold_prologue(p.in_fin, Lb == 0);          // (before anything is live: an out-of-line call)
     const int SPT = p.nchunks * p.nstg;
     const int total = nun * SPT;
     const int npix = p.PH * p.PW;
@@ -714,7 +712,7 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
     if ((d->Hl - 1) * d->out_sh + d->out_oh >= d->Hout || (d->Wl - 1) * d->out_sw + d->out_ow >= d->Wout) return MFC_ERR_INVALID_ARG;
     if (d->images_per_group <= 0 || d->N % d->images_per_group) return MFC_ERR_INVALID_ARG;
     k.in = (const char*)d->in; k.wp = (const char*)d->wp; k.out = (char*)d->out;
-    k.bias = d->bias; k.in_coef = d->in_coef; k.out_stats = d->out_stats; k.in_fin = (const mfc_bnfin_desc*)d->in_fin;
+    k.bias = d->bias; k.in_coef = d->in_coef; k.out_stats = d->out_stats;
     k.N = d->N; k.Hin = d->Hin; k.Win = d->Win; k.Cin_p = d->Cin_p; k.Cin_g = ceil_div(d->Cin, E);
     k.Hout = d->Hout; k.Wout = d->Wout; k.Cout_p = d->Cout_p; k.Cout = d->Cout;
     k.Hl = d->Hl; k.Wl = d->Wl; k.TA = d->TA; k.TB = d->TB; k.dh0 = d->dh0; k.dw0 = d->dw0; k.s = d->in_stride;
@@ -957,8 +955,7 @@ static int conv_dispatch(const ConvK& k, int MT, int PM, int NW, size_t lds, int
 
 extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
     if (!d) return MFC_ERR_INVALID_ARG;
-    if (d->in_fin && !d->in_coef) return MFC_ERR_INVALID_ARG;        // a folded finalize writes the block this launch reads as in_coef
-    if (!mfc_ptrs_ok(d->in, d->wp, d->out, d->bias, d->in_coef, d->out_stats, d->acc_src, d->bn_y, d->bn_coef, d->bn_bits, d->in_fin)) return MFC_ERR_INVALID_ARG;
+    if (!mfc_ptrs_ok(d->in, d->wp, d->out, d->bias, d->in_coef, d->out_stats, d->acc_src, d->bn_y, d->bn_coef, d->bn_bits)) return MFC_ERR_INVALID_ARG;
     if (ring_eligible(d)) return ring_launch(d, (hipStream_t)stream);
     const bool fused = d && (d->acc_src || d->bn_y);
     if (d && gemm1x1_eligible(d)) return fused ? MFC_ERR_UNSUPPORTED : gemm1x1_launch(d, (hipStream_t)stream);

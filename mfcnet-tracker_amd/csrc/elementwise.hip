@@ -226,76 +226,6 @@ __global__ __launch_bounds__(256) void combine_same_kernel(mfc_combine_desc d, l
     }
 }
 
-// The same pass with a folded BatchNorm finalize (d.fin): the prologue is paid per workgroup, so at most 1024 workgroups, each with ONE
-// contiguous range of `per_block` granules (a multiple of 8 = whole 128-byte lines); the loads of its first 1024 granules are issued
-// before the finalize, whose dependent replica reads then run under them.  (Without a finalize the one-shot form above is faster:
-// 17.8 vs 22.6 us on a 32-channel 120x160 tensor -- twice the waves in flight per CU.)
-template <typename T>
-__global__ __launch_bounds__(256) void combine_same_fin_kernel(mfc_combine_desc d, unsigned total, int Cg, unsigned per_block, int wt) {
-    constexpr int E = Gran<T>::E;
-    constexpr int U = 4;
-    const unsigned lo = blockIdx.x * per_block;
-    const unsigned hi = (lo + per_block < total) ? lo + per_block : total;          // (host: lo < total)
-    const unsigned ppg = (unsigned)d.images_per_group * d.out.H * d.out.W;
-    uint4 r[U][4]; unsigned pix[U]; int gq[U];
-    auto load = [&](unsigned base) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            unsigned idx = base + u * 256u;
-            if (idx >= hi) idx = hi - 1;
-            pix[u] = idx / (unsigned)Cg; gq[u] = (int)(idx - pix[u] * (unsigned)Cg);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < d.nsrc) r[u][k] = *(const uint4*)((const char*)d.src[k].ptr + ((size_t)pix[u] * d.src[k].Cp + d.src[k].c_off + gq[u] * E) * sizeof(T));
-        }
-    };
-    load(lo + threadIdx.x);
-    if (d.fin) bn_fold_body((const mfc_bnfin_desc*)d.fin, blockIdx.x == 0);
-    for (unsigned base = lo + threadIdx.x; ; ) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (base + u * 256u >= hi) break;
-            const int grp = (int)(pix[u] / ppg);
-            float acc[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < d.nsrc) {
-                    float f[E];
-                    Gran<T>::unpack(r[u][k], f);
-                    if (d.src[k].coef) {
-                        const float* cf = (const float*)d.src[k].coef + (size_t)grp * 4 * d.src[k].Cp + d.src[k].c_off + gq[u] * E;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) f[e] = f[e] * cf[e] + cf[d.src[k].Cp + e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < E; ++e) acc[e] += f[e];
-                }
-            }
-            if (d.relu == 1) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) acc[e] = relu_nan(acc[e]);
-            } else if (d.relu == 2) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) acc[e] = silu_f(acc[e]);
-            }
-            mfc_st16_if(((char*)d.out.ptr + ((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) * sizeof(T)), Gran<T>::pack(acc), wt);
-            if constexpr (E == 8) {
-                if (d.maskbits) {       // the ReLU mask of the backward pass: one bit per element
-                    unsigned b = 0;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) b |= (acc[e] > 0.f ? 1u : 0u) << e;
-                    ((unsigned char*)d.maskbits)[((size_t)pix[u] * d.out.Cp + d.out.c_off + gq[u] * E) >> 3] = (unsigned char)b;
-                }
-            }
-        }
-        base += 256u * U;
-        if (base - threadIdx.x >= hi) break;          // (block-uniform)
-        load(base);
-    }
-}
-
 static bool view_ok(const mfc_view& v, int E) { return v.ptr && v.H > 0 && v.W > 0 && v.Cp % 8 == 0 && v.c_off % E == 0; }
 
 extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
@@ -305,7 +235,7 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
     if (!view_ok(d->out, E) || d->C <= 0 || d->C % E || d->N <= 0 || d->images_per_group <= 0) return MFC_ERR_INVALID_ARG;
     if (d->out.c_off + d->C > d->out.Cp) return MFC_ERR_INVALID_ARG;
     if (!mfc_ptrs_ok(d->out.ptr, d->src[0].ptr, d->src[0].coef, d->src[1].ptr, d->src[1].coef, d->src[2].ptr, d->src[2].coef, d->src[3].ptr, d->src[3].coef,
-                     d->maskbits, d->fin)) return MFC_ERR_INVALID_ARG;
+                     d->maskbits)) return MFC_ERR_INVALID_ARG;
     for (int k = 0; k < d->nsrc; ++k)
         if (!view_ok(d->src[k], E) || d->src[k].c_off + d->C > d->src[k].Cp) return MFC_ERR_INVALID_ARG;
     const int Cg = d->C / E;
@@ -318,18 +248,6 @@ extern "C" int mfc_combine_fwd(const mfc_combine_desc* d, void* stream) {
     double cbytes = view_bytes(d->out, d->N, d->C, E == 8 ? 2 : 4) + (d->maskbits ? (double)total : 0.0);
     for (int k = 0; k < d->nsrc; ++k) cbytes += view_bytes(d->src[k], d->N, d->C, E == 8 ? 2 : 4);
     const int wt = mfc_wt_for((double)total * 16.0);                 // write-through stores for a large output (common.h)
-    if (d->fin && (!same || d->C > 256)) return MFC_ERR_UNSUPPORTED;     // the folded finalize lives in the same-resolution kernel
-    if (same && d->fin) {
-        const long nch = (total + 1023) / 1024;
-        int b2 = nch < 1024 ? (int)nch : 1024;
-        const unsigned per_block = (unsigned)(((total + b2 - 1) / b2 + 7) / 8 * 8);
-        b2 = (int)((total + per_block - 1) / per_block);
-        EW_PROF(st, "combine_same_fin_kernel", d->dtype, cbytes);
-        MFC_TYPED(d->dtype, T_, hipLaunchKernelGGL(combine_same_fin_kernel<T_>, dim3(b2), dim3(256), 0, st, *d, (unsigned)total, Cg, per_block, wt));
-        MFC_PROF_END(st);
-        MFC_CHECK_LAUNCH();
-        return MFC_OK;
-    }
     if (same) {
         const int b2 = (int)((total + 511) / 512);
         EW_PROF(st, "combine_same_kernel", d->dtype, cbytes);

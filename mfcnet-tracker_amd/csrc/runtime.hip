@@ -671,7 +671,7 @@ static int program_run(const mfc_op* ops, int32_t n, void* stream, bool defer_jo
     // A program WITHOUT detached records (the forward pass: no weight gradients) leaves the detached stream -- the fourth hardware queue -- idle:
     // the fourth branch of a module (lane 4, otherwise folded onto the main stream) may run there (mfc_set_flag(56, 1)).
     bool has_async = false;
-    for (int i = 0; i < n && !has_async; ++i) has_async = (ops[i].lane & MFC_LANE_ASYNC) != 0;
+    for (int i = 0; i < n && !has_async && (g_lanes_on & 2); ++i) has_async = (ops[i].lane & MFC_LANE_ASYNC) != 0;
     const bool lane4_detached = multi && g_lane4_fwd && !has_async && !(L && L->pending) && !g_capturing;
     auto side = [&](int l) -> hipStream_t { return (lane4_detached && l == 4) ? L->as[0] : L->s[l]; };
     bool in_par = false; unsigned used = 0;

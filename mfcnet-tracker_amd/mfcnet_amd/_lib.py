@@ -22,7 +22,7 @@ F32, BF16, F16 = 0, 1, 2
 def is16(dtype: int) -> bool:
     """16-bit storage (bf16 or fp16): 8 channels per 16-byte granule, MFMA 16x16x32 kernels."""
     return dtype in (BF16, F16)
-STAT_REPLICAS = 8
+STAT_REPLICAS = int(os.environ.get("MFC_STAT_REPLICAS", "8"))      # must equal the library's MFC_STAT_REPLICAS (A/B builds: make REPLICAS=n OUT=...)
 STAT_BYTES = 8            # sizeof(mfc_stat_t): the statistic cells are fp64
 LOSS_ACC_FLOATS = 96      # MFC_LOSS_ACC_FLOATS: 32 result floats + the scratch of mfc_loss_partial
 
@@ -49,8 +49,7 @@ class ConvDesc(C.Structure):
                 ("TA", i32), ("TB", i32), ("dh0", i32), ("dw0", i32), ("in_stride", i32),
                 ("out_sh", i32), ("out_sw", i32), ("out_oh", i32), ("out_ow", i32),
                 ("in_relu", i32), ("images_per_group", i32), ("accumulate", i32), ("TH", i32), ("TW", i32),
-                ("acc_src", vp), ("bn_y", vp), ("bn_coef", vp), ("bn_bits", vp), ("bn_mask_mode", i32), ("flags", i32),
-                ("in_fin", vp)]
+                ("acc_src", vp), ("bn_y", vp), ("bn_coef", vp), ("bn_bits", vp), ("bn_mask_mode", i32), ("flags", i32)]
 
 
 class PackJob(C.Structure):
@@ -96,7 +95,7 @@ class View(C.Structure):
 
 class CombineDesc(C.Structure):
     _fields_ = [("out", View), ("src", View * 4), ("nsrc", i32), ("relu", i32), ("dtype", i32),
-                ("N", i32), ("C", i32), ("images_per_group", i32), ("maskbits", u64), ("fin", u64)]
+                ("N", i32), ("C", i32), ("images_per_group", i32), ("maskbits", u64)]
 
 
 class BnBwdDesc(C.Structure):

@@ -79,9 +79,6 @@ class BN:
     coef: int
     bstats: int
     bcoef: int
-    fin_rec: object = None       # the stand-alone BNFIN descriptor emitted behind the producer (until a consumer takes it over)
-    fin_lane: int = 0
-    fold_lane: Optional[int] = None      # lane of the consumer launch the finalize was folded into
 
 
 @dataclass
@@ -171,16 +168,9 @@ class Plan:
         # BatchNorm-backward reduce passes folded into the epilogue of the data-gradient launch that completes the gradient (bf16):
         # mfc_conv_desc.bn_y / acc_src (include/mfcnet_hip.h)
         self.fuse_bnred = bool(getattr(model, "fuse_bnbwd_reduce", True)) and L.is16(self.dtype) and need_backward
-        # BatchNorm finalizes folded into their consumer's launch (mfc_conv_desc.in_fin / mfc_combine_desc.fin): the training-mode
-        # BNFIN record between a producer convolution and the FIRST reader of its coefficient block disappears when that reader runs
-        # on the same lane and is a convolution or a same-resolution combine (include/mfcnet_hip.h)
-        # OFF by default -- measured (profiles/r03_fold_bn_finalize.txt): the redundant per-workgroup prologue (descriptor read -> replica
-        # sums -> fp64 sqrt -> coefficient write -> read back) costs a convolution +2..4 us and a combine +5..9 us against the 3.7 us
-        # launch it removes: serial forward 12.3 -> 12.7 ms, step and b=1 step unchanged.
-        self.fold_fin = bool(getattr(model, "fold_bn_finalize", False))
         # data gradient of a 3x3 / stride-2 convolution as ONE launch over its four output parity classes instead of four launches (round 4)
         self.merge_s2 = bool(getattr(model, "merge_s2_dgrad", True))
-        self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc", "fin")}
+        self.arenas = {k: Arena(k) for k in ("act", "stats", "bstats", "dwp", "misc")}
         self.dry = dry
         self._build()                       # sizing pass
         if dry:
@@ -238,33 +228,6 @@ class Plan:
 
     def view(self, t: Ten, bn: Optional[BN] = None, c_off=0) -> L.View:
         return L.View(t.ptr, bn.coef if bn else 0, t.H, t.W, t.Cp, c_off)
-
-    def _fold_fin(self, bn: Optional[BN], max_C=None) -> int:
-        """A forward record about to be emitted reads bn's coefficient block.  If bn's stand-alone finalize can move into that record
-        (training mode, producer and reader on the same lane, nobody read the block before), retract the BNFIN record and return the
-        DEVICE address of its descriptor row; 0 otherwise.  Later readers of a folded block must run on the folding lane (stream
-        order is then the only ordering they need): anything else would race and is refused at plan time."""
-        if bn is None:
-            return 0
-        if bn.fold_lane is not None:
-            if bn.fold_lane != self.cur_lane:
-                raise L.MfcError(f"plan: BatchNorm {bn.name} was finalized inside a launch of lane {bn.fold_lane} and is read again on lane {self.cur_lane}")
-            return 0
-        rec, bn.fin_rec = bn.fin_rec, None          # (whatever happens below, this reader is the first: later ones never fold)
-        if rec is None or not self.fold_fin or not bn.training or bn.fin_lane != self.cur_lane or not (1 <= bn.G <= 8):
-            return 0
-        if max_C is not None and bn.C > max_C:
-            return 0
-        for i in range(len(self.fwd) - 1, -1, -1):
-            if self.fwd[i][1] is rec:
-                del self.fwd[i]
-                break
-        else:
-            return 0
-        off = self.arenas["fin"].alloc(128)
-        self._fin_rows.append((off, rec))
-        bn.fold_lane = self.cur_lane
-        return self.arenas["fin"].base + off
 
     # ------------------------------------------------------------------ conv bookkeeping
     def _pack(self, desc, src, cout, cin, k, **tap):
@@ -400,7 +363,6 @@ class Plan:
                        bn.stats if (bn and bn.training) else 0, self.dtype, xt.N, xt.H, xt.W, xt.Cp, xt.C,
                        Ho, Wo, y.Cp, cout, Ho, Wo, k, k, -pad, -pad, stride, 1, 1, 0, 0,
                        1 if x.relu else 0, xt.ipg, 0, 0, 0)
-        d.in_fin = self._fold_fin(x.bn)
         ci = self.conv_info(d, xt, y, wname, cout, xt.C, k, stride, bias, x.bn.coef if x.bn else 0, 1 if x.relu else 0)
         ci.fwd = d
         self.fwd.append((L.OP_CONV, d))
@@ -411,7 +373,6 @@ class Plan:
                              self.m._NBT.data_ptr() + 8 * self.m._noff[bn_name + ".num_batches_tracked"],
                              bn.C, bn.Cp, bn.G, 1 if bn.training else 0, bn.count, BN_EPS, BN_MOMENTUM)
             self.fwd.append((L.OP_BNFIN, fd))
-            bn.fin_rec, bn.fin_lane = fd, self.cur_lane          # (the first reader of bn.coef may take it over: _fold_fin)
             self.ops.append(("bnfin", y, bn))
         return Act(y, bn, False)
 
@@ -434,14 +395,6 @@ class Plan:
         for i, tm in enumerate(terms):
             d.src[i] = self.view(tm.t, tm.bn, tm.c_off)
         d.nsrc, d.relu, d.dtype, d.N, d.C, d.images_per_group = len(terms), 1 if relu else 0, self.dtype, out.N, Cs, out.ipg
-        same_res = all((tm.t.H, tm.t.W) == (out.H, out.W) for tm in terms)
-        for tm in terms:
-            if tm.bn is None:
-                continue
-            if same_res and not d.fin:
-                d.fin = self._fold_fin(tm.bn, max_C=256)
-            else:
-                self._fold_fin(tm.bn, max_C=-1)              # (a reader all the same: checks the lane rule, folds nothing)
         if relu and self.need_backward and L.is16(self.dtype) and self.mask_bits:
             # the backward of the summed terms (BatchNorm reduce, masked adds / up-sampling adjoints) needs only the sign of this
             # output: keep it as one bit per element (1/16 of the tensor) so that those passes read one tensor less
@@ -459,7 +412,6 @@ class Plan:
         self.cur_lane = 0
         self.fwd, self.bwd, self.ops = _Recs(self), _Recs(self), _Ops(self)
         self.pack_jobs, self.unpack_jobs = [], []
-        self._fin_rows = []
         m, B, T, H, W, nc = self.m, self.B, self.T, self.H, self.W, self.nc
         self.grad_base = m._G.data_ptr()
         f32 = lambda n: self._alloc("misc", 4 * n)
@@ -863,13 +815,6 @@ class Plan:
 
     def _finalize(self):
         st, bs, dw = self.arenas["stats"], self.arenas["bstats"], self.arenas["dwp"]
-        if self._fin_rows:                                   # descriptor rows of the folded BatchNorm finalizes: one upload
-            fa = self.arenas["fin"]
-            img = bytearray(fa.size)
-            for off, rec in self._fin_rows:
-                img[off:off + C.sizeof(rec)] = bytes(rec)
-            o = fa.base - fa.buf.data_ptr()
-            fa.buf[o:o + len(img)].copy_(torch.frombuffer(img, dtype=torch.uint8))
         self._pack_dev, npk, nbk = self._jobs(self.pack_jobs, L.PackJob, 256)
         pro = []
         r = L.RawOp(st.base, 0, 0, st.size)

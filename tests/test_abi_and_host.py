@@ -154,15 +154,6 @@ def test_plan_builds_without_gpu():
     p = Plan(m, 2, 64, 96, True, True, True, True, True, torch.device("cpu"))
     kinds = [o.kind for o in p.fwd_prog]
     assert kinds.count(L.OP_CONV) == 311 and kinds.count(L.OP_BNFIN) == 309        # 307 + 4 convs
-    # optional (model.fold_bn_finalize, off by default): a training-mode finalize rides in the prologue of the first launch that reads its
-    # coefficient block (mfc_conv_desc.in_fin / mfc_combine_desc.fin): the BasicBlock / Bottleneck chains fold, the cross-lane fuse paths do not
-    m.fold_bn_finalize = True
-    p1 = Plan(m, 2, 64, 96, True, True, True, True, True, torch.device("cpu"))
-    k1 = [o.kind for o in p1.fwd_prog]
-    folded = sum(1 for o in p1.fwd_prog if (o.kind == L.OP_CONV and o.u.conv.in_fin) or (o.kind == L.OP_COMBINE and o.u.combine.fin))
-    assert k1.count(L.OP_BNFIN) + folded == 309 and folded >= 208 and len(k1) == len(kinds) - folded
-    assert all(o.u.conv.in_coef for o in p1.fwd_prog if o.kind == L.OP_CONV and o.u.conv.in_fin)
-    m.fold_bn_finalize = False
     bk = [o.kind for o in p.bwd_prog]
     assert bk.count(L.OP_WGRAD) == 311 and bk[-1] == L.OP_UNPACK
     # every BatchNorm has an apply record; its reduce is either a record of its own or folded into the data-gradient launch that

@@ -579,31 +579,6 @@ def test_lanes_do_not_change_results(mfc):
     assert torch.equal(y0, y1) and torch.equal(g0, g1)
 
 
-def test_folded_bn_finalize_does_not_change_results(mfc):
-    """`model.fold_bn_finalize = True` (off by default: measured no faster) moves 246 of the 309 training-mode BatchNorm
-    finalizes into the prologue of the launch that first reads their coefficients (mfc_conv_desc.in_fin / mfc_combine_desc.fin): same
-    logits, same gradients, same running statistics, bit for bit."""
-    from mfcnet_amd import _lib as L
-    cfg, z = load_case("large_rgb_train")
-    frames, flows, depths, mask = case_inputs(cfg)
-    res = []
-    for fold in (False, True):
-        m = build(mfc, cfg)
-        m.fold_bn_finalize = fold
-        set_mode(m, "train")
-        y = m(dev(frames))
-        loss, _ = mfc.mfc_loss(y, mask.cuda())
-        loss.backward()
-        torch.cuda.synchronize()
-        prog = next(iter(m._plans.values())).fwd_prog
-        nfold = sum(1 for o in prog if (o.kind == L.OP_CONV and o.u.conv.in_fin) or (o.kind == L.OP_COMBINE and o.u.combine.fin))
-        assert (nfold >= 208) == fold and (nfold == 0) == (not fold)
-        bufs = torch.cat([b.detach().flatten().float().cpu() for n, b in m.named_buffers() if "running_" in n])
-        res.append((y.detach().cpu(), m._G.detach().cpu().clone(), bufs))
-    for a, b in zip(res[0], res[1]):
-        assert torch.equal(a, b)
-
-
 def test_hoisted_eval_bn_finalize_is_bit_identical(mfc):
     """Eval-mode BatchNorm finalizes run as ONE table launch in front of the program (mfc_bn_finalize_batch); the logits are
     those of the per-record form -- bit for bit in full eval mode; with only the base model frozen (engine.py:25-26) up to

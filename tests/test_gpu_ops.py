@@ -485,105 +485,6 @@ def test_bn_finalize_matches_batch_norm(M):
     assert float((y * c[0, 0].view(1, -1, 1, 1) + c[0, 1].view(1, -1, 1, 1) - ref).abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize("case", [(32, 3, 20, 24, 1), (64, 3, 12, 16, 1), (128, 3, 9, 10, 1), (24, 3, 11, 13, 1), (64, 1, 16, 16, 1), (64, 3, 12, 16, 2)],
-                         ids=["ring32", "ring64", "igemm128", "igemm24", "1x1", "stride2"])
-@pytest.mark.parametrize("dtype", DT)
-def test_folded_bn_finalize_conv(M, dtype, case):
-    """mfc_conv_desc.in_fin: the producer's BatchNorm finalize inside the consumer convolution (every kernel that takes an input
-    transform: conv3x3_ring, conv_igemm, conv_gemm1x1) gives the SAME BITS -- output, coefficient block, running statistics,
-    num_batches_tracked -- as mfc_bn_finalize followed by the plain launch (hrnet.py:62-66: bn1 -> relu -> conv2)."""
-    import ctypes as C
-    _, L, ops = M
-    Cc, k, H, W, stride = case
-    if dtype == torch.float32 and Cc > 64:
-        pytest.skip("fp32 parity mode: small channel counts only")
-    G, ipg = 3, 2
-    N = G * ipg
-    g = torch.Generator().manual_seed(41)
-    x = ops.to_nhwc(torch.randn(N, Cc, H, W, generator=g) * 1.5 + 0.3, dtype)
-    w = (torch.randn(Cc, Cc, k, k, generator=g) * 0.1).cuda()
-    xf = x.float()
-    R = L.STAT_REPLICAS
-    stats = torch.zeros(R, G, 2, x.shape[3], dtype=torch.float64, device="cuda")
-    for gi in range(G):            # the sums a producer convolution's epilogue would have left, spread over replica rows
-        xx = xf[gi * ipg:(gi + 1) * ipg].double()
-        stats[gi % R, gi, 0] = xx.sum((0, 1, 2))
-        stats[(gi + 3) % R, gi, 1] = (xx * xx).sum((0, 1, 2))
-    gamma, beta = (torch.rand(Cc, generator=g) + 0.5).cuda(), (torch.randn(Cc, generator=g) * 0.3).cuda()
-    pad = k // 2
-    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    res = []
-    for fold in (False, True):
-        coef = torch.zeros(G, 4, x.shape[3], device="cuda")
-        rm, rv = torch.full((Cc,), 0.25, device="cuda"), torch.full((Cc,), 1.5, device="cuda")
-        nbt = torch.zeros((), dtype=torch.int64, device="cuda")
-        fd = L.BnFinDesc(stats.data_ptr(), coef.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
-                         nbt.data_ptr(), Cc, x.shape[3], G, 1, float(ipg * H * W), 1e-5, 0.1)
-        out = torch.zeros(N, Ho, Wo, x.shape[3], dtype=x.dtype, device="cuda")
-        d = L.ConvDesc(x.data_ptr(), 0, out.data_ptr(), 0, coef.data_ptr(), 0, ops.dt_of(x), N, H, W, x.shape[3], Cc, Ho, Wo, out.shape[3], Cc,
-                       Ho, Wo, k, k, -pad, -pad, stride, 1, 1, 0, 0, 1, ipg, 0, 0, 0)
-        if fold:
-            fdev = torch.frombuffer(bytearray(bytes(fd)), dtype=torch.uint8).cuda()
-            d.in_fin = fdev.data_ptr()
-        else:
-            L.call(L.lib.mfc_bn_finalize, fd)
-        wp = ops.pack_weight(w, d, "fwd")
-        d.wp = wp.data_ptr()
-        L.call(L.lib.mfc_conv2d_fwd, d)
-        torch.cuda.synchronize()
-        res.append((out.clone(), coef.clone(), rm.clone(), rv.clone(), int(nbt)))
-    for a, b in zip(res[0][:4], res[1][:4]):
-        assert torch.equal(a, b)
-    assert res[0][4] == res[1][4] == G
-    d.in_coef = 0                                   # a folded finalize without the block it writes: refused, not ignored
-    assert L.lib.mfc_conv2d_fwd(C.byref(d), L.stream_ptr()) == -1
-
-
-@pytest.mark.parametrize("Cc", [32, 64, 256])
-@pytest.mark.parametrize("dtype", DT)
-def test_folded_bn_finalize_combine(M, dtype, Cc):
-    """mfc_combine_desc.fin: bn2 of a BasicBlock finalized inside the residual add (hrnet.py:66-72): same bits as the two launches."""
-    _, L, ops = M
-    G, ipg, H, W = 3, 2, 14, 18
-    N = G * ipg
-    g = torch.Generator().manual_seed(43)
-    y = ops.to_nhwc(torch.randn(N, Cc, H, W, generator=g) * 2 - 0.2, dtype)
-    idn = ops.to_nhwc(torch.randn(N, Cc, H, W, generator=g), dtype)
-    R = L.STAT_REPLICAS
-    stats = torch.zeros(R, G, 2, Cc, dtype=torch.float64, device="cuda")
-    for gi in range(G):
-        yy = y.float()[gi * ipg:(gi + 1) * ipg].double()
-        stats[(gi + 1) % R, gi, 0] = yy.sum((0, 1, 2))
-        stats[(gi + 6) % R, gi, 1] = (yy * yy).sum((0, 1, 2))
-    gamma, beta = (torch.rand(Cc, generator=g) + 0.5).cuda(), (torch.randn(Cc, generator=g) * 0.3).cuda()
-    res = []
-    for fold in (False, True):
-        coef = torch.zeros(G, 4, Cc, device="cuda")
-        rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
-        nbt = torch.zeros((), dtype=torch.int64, device="cuda")
-        fd = L.BnFinDesc(stats.data_ptr(), coef.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
-                         nbt.data_ptr(), Cc, Cc, G, 1, float(ipg * H * W), 1e-5, 0.1)
-        out = torch.zeros_like(y)
-        d = L.CombineDesc()
-        d.out = L.View(out.data_ptr(), 0, H, W, Cc, 0)
-        d.src[0] = L.View(y.data_ptr(), coef.data_ptr(), H, W, Cc, 0)
-        d.src[1] = L.View(idn.data_ptr(), 0, H, W, Cc, 0)
-        d.nsrc, d.relu, d.dtype, d.N, d.C, d.images_per_group = 2, 1, ops.dt_of(y), N, Cc, ipg
-        if fold:
-            fdev = torch.frombuffer(bytearray(bytes(fd)), dtype=torch.uint8).cuda()
-            d.fin = fdev.data_ptr()
-        else:
-            L.call(L.lib.mfc_bn_finalize, fd)
-        L.call(L.lib.mfc_combine_fwd, d)
-        torch.cuda.synchronize()
-        res.append((out.clone(), coef.clone(), rm.clone(), rv.clone(), int(nbt)))
-    for a, b in zip(res[0][:4], res[1][:4]):
-        assert torch.equal(a, b)
-    assert res[0][4] == res[1][4] == G
-    ref = torch.relu(F.batch_norm(ops.to_nchw(y, Cc)[:ipg].cpu(), None, None, gamma.cpu(), beta.cpu(), True, 0.1, 1e-5) + ops.to_nchw(idn, Cc)[:ipg].cpu())
-    assert relerr(ops.to_nchw(res[1][0], Cc)[:ipg].cpu(), ref) < TOL[dtype]
-
-
 @pytest.mark.parametrize("dtype", DT)
 def test_combine_residual_bilinear(M, dtype):
     """fuse-layer sum: identity + BN(up-sampled conv output) + BN(same-res conv output), ReLU (hrnet.py:245-260)."""
@@ -1027,7 +928,7 @@ def test_invalid_descriptors_are_rejected(M):
 
 def test_placeholder_pointers_are_refused_not_faulted():
     """Round 3's aborts (gpurun_out/r03_t5.log, r03_t6.log): descriptors cloned from a DRY plan carried its placeholder address (1 << 30 + offset) in
-    mfc_conv_desc.in_fin / mfc_combine_desc.fin; bn_fold_prologue dereferenced it and the GPU faulted at the next synchronisation.  With the
+    mfc_conv_desc.in_fin / mfc_combine_desc.fin (fields of round 3's folded BatchNorm finalize, removed in round 4); bn_fold_prologue dereferenced it and the GPU faulted at the next synchronisation.  With the
     descriptor hardening on (the GPU test session's default) such a launch is refused."""
     from mfcnet_amd import _lib as L, ops
     import ctypes as C
@@ -1040,9 +941,9 @@ def test_placeholder_pointers_are_refused_not_faulted():
     wp = ops.pack_weight(w, d, "fwd")
     d.wp = wp.data_ptr()
     assert L.lib.mfc_conv2d_fwd(C.byref(d), L.stream_ptr()) == 0
-    d.in_fin = (1 << 30) + 4096                       # a dry plan's "fin" arena
+    d.in_coef = (1 << 30) + 4096                      # a dry plan's placeholder address
     assert L.lib.mfc_conv2d_fwd(C.byref(d), L.stream_ptr()) == -1
-    d.in_fin = 0
+    d.in_coef = coef.data_ptr()
     host = torch.zeros(64)
     d.bias = host.data_ptr()                          # a host tensor's address
     assert L.lib.mfc_conv2d_fwd(C.byref(d), L.stream_ptr()) == -1
@@ -1051,6 +952,6 @@ def test_placeholder_pointers_are_refused_not_faulted():
     cd.src[0] = L.View(x.data_ptr(), 0, 8, 8, 32, 0)
     cd.nsrc, cd.relu, cd.dtype, cd.N, cd.C, cd.images_per_group = 1, 1, L.BF16, 2, 32, 2
     assert L.lib.mfc_combine_fwd(C.byref(cd), L.stream_ptr()) == 0
-    cd.fin = (1 << 30) + 128
+    cd.src[0] = L.View(x.data_ptr(), (1 << 30) + 128, 8, 8, 32, 0)          # a placeholder coefficient block
     assert L.lib.mfc_combine_fwd(C.byref(cd), L.stream_ptr()) == -1
     torch.cuda.synchronize()

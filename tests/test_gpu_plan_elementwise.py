@@ -104,7 +104,6 @@ def run_combine(d0, L, gen):
     ref = F.relu(acc) if d.relu == 1 else acc
     assert d.relu in (0, 1)
     d.out = L.View(out_d.data_ptr(), 0, H, W, d.out.Cp, d.out.c_off)
-    d.fin = 0               # (the plan's folded finalize points into the dry plan's descriptor arena; tests/test_gpu_ops.py covers it)
     bits = None
     if d.maskbits:
         bits = torch.full((N * H * W * d.out.Cp // 8,), 0xAA, dtype=torch.uint8, device="cuda")

@@ -109,7 +109,6 @@ def run_node(ci, L, ops, seed):
     d.inp, d.out = xd.data_ptr(), out.data_ptr()
     d.bias = bias_d.data_ptr() if bias_d is not None else 0
     d.in_coef = coef_d.data_ptr() if coef_d is not None else 0
-    d.in_fin = 0            # (the folded finalize of the plan points into the dry plan's descriptor arena; tests/test_gpu_ops.py covers it)
     d.out_stats = stats.data_ptr() if stats is not None else 0
     wp = ops.pack_weight(w.cuda(), d, "fwd")
     d.wp = wp.data_ptr()

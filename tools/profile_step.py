@@ -27,7 +27,7 @@ def describe(o, esz):
         d = o.u.conv
         fl = 2.0 * d.N * d.Hl * d.Wl * d.Cout * d.TA * d.TB * d.Cin
         tag = f"conv N{d.N} {d.Cin}->{d.Cout} k{d.TA}x{d.TB} in{d.Hin}x{d.Win} loc{d.Hl}x{d.Wl} s{d.in_stride} os{d.out_sh}" \
-              f"{' xf' if d.in_coef else ''}{' fin' if d.in_fin else ''}{' st' if d.out_stats else ''}{' acc' if d.accumulate else ''}{' b' if d.bias else ''}"
+              f"{' xf' if d.in_coef else ''}{' st' if d.out_stats else ''}{' acc' if d.accumulate else ''}{' b' if d.bias else ''}"
         by = d.N * (d.Hin * d.Win * d.Cin_p / (d.out_sh * d.out_sw) + d.Hl * d.Wl * d.Cout_p) * esz
         return tag, fl, by
     if k == 2:
@@ -43,7 +43,7 @@ def describe(o, esz):
         for i in range(d.nsrc):
             src += d.N * d.src[i].H * d.src[i].W * d.C * esz
         res = ",".join(f"{d.src[i].H}" for i in range(d.nsrc))
-        return f"combine N{d.N} C{d.C} {d.out.H}x{d.out.W} src[{res}]{' fin' if d.fin else ''}", 0.0, by + src
+        return f"combine N{d.N} C{d.C} {d.out.H}x{d.out.W} src[{res}]", 0.0, by + src
     if k in (5, 7):
         d = o.u.bnbwd
         n = d.N * d.g.H * d.g.W * d.C * esz
