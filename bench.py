@@ -328,7 +328,7 @@ def main():
         fill_hashed(model)                                      # every state_dict entry a pure function of its key
     model = model.to(device)
     model = model.eval() if args.fwd_only else model.train()
-    for env, attr in (("MFC_MASK_BITS", "relu_mask_bits"), ("MFC_BATCH_WGRAD", "batch_wgrad"), ("MFC_FUSE_BNRED", "fuse_bnbwd_reduce"), ("MFC_MERGE_S2", "merge_s2_dgrad")):      # tuning switches of the plan
+    for env, attr in (("MFC_MASK_BITS", "relu_mask_bits"), ("MFC_BATCH_WGRAD", "batch_wgrad"), ("MFC_FUSE_BNRED", "fuse_bnbwd_reduce"), ("MFC_MERGE_S2", "merge_s2_dgrad"), ("MFC_ONE_JOIN", "fuse_one_join")):      # tuning switches of the plan
         if os.environ.get(env):
             setattr(model, attr, os.environ[env] != "0")
     opt = mfc.FlatAdam(model, lr=1e-4)

@@ -477,7 +477,9 @@ typedef enum {
     MFC_OP_UPNEAR = 21,          /* raw.a = src, raw.b = dst, raw.i = dtype, N, H, W, Cp */
     MFC_OP_GNBWD_FIN = 22,       /* gnbwdfin */
     MFC_OP_WSBWD = 23,           /* raw.a = w, raw.b = dws, raw.c = dw, raw.i[0] = Cout, raw.i[1] = per_out, raw.i[2] = eps (float bits) */
-    MFC_OP_UPNEAR_BWD = 24       /* raw.a = dsrc, raw.b = ddst, raw.i = dtype, N, H, W, Cp, accumulate */
+    MFC_OP_UPNEAR_BWD = 24,      /* raw.a = dsrc, raw.b = ddst, raw.i = dtype, N, H, W, Cp, accumulate */
+    MFC_OP_JOIN = 25             /* no launch: a lane-0 record that ends a parallel section (all side lanes are joined into the main stream) where the next
+                                  * records, on lanes again, depend on several lanes of the section before (module fuse sums, hrnet.py:245-260) */
 } mfc_op_kind;
 
 #define MFC_LANE_ASYNC 0x100

@@ -428,6 +428,7 @@ static int run_one(const mfc_op& o, void* stream) {
         case MFC_OP_UPNEAR_BWD:  // a = dsrc, b = ddst, i = dtype, N, H, W, Cp, accumulate
             return mfc_upsample_nearest2x_bwd((const void*)o.u.raw.a, (void*)o.u.raw.b, o.u.raw.i[0], o.u.raw.i[1], o.u.raw.i[2], o.u.raw.i[3], o.u.raw.i[4],
                                               o.u.raw.i[5], stream);
+        case MFC_OP_JOIN: return MFC_OK;          // (the interpreter joins the side lanes at any lane-0 record: nothing to launch)
         default: return MFC_ERR_INVALID_ARG;
     }
 }

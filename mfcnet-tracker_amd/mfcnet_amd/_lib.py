@@ -33,7 +33,7 @@ OP_HEAD_FWD, OP_HEAD_BWD, OP_BIAS_GRAD, OP_MEMSET, OP_PACK, OP_UNPACK, OP_NCHW2N
 OP_WGRAD_BATCH = 17
 OP_BNFIN_BATCH = 18
 OP_WSNORM, OP_GNFIN, OP_UPNEAR = 19, 20, 21
-OP_GNBWD_FIN, OP_WSBWD, OP_UPNEAR_BWD = 22, 23, 24
+OP_GNBWD_FIN, OP_WSBWD, OP_UPNEAR_BWD, OP_JOIN = 22, 23, 24, 25
 WGRAD_MAXBATCH = 8
 CONV_WANT_FA = 1
 CONV_S2_CLASSES = 2      # mfc_conv_desc.flags: data gradient of a 3x3 / stride-2 convolution, all four output parity classes in one launch

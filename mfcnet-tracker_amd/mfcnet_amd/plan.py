@@ -520,13 +520,14 @@ class Plan:
                     v = self.combine([Term(o.t, o.bn), Term(v.t)], True)
                 xs[i] = v
             self.cur_lane = 0
-            outs = []
+            one_join = self.lanes and getattr(self.m, "fuse_one_join", True)
+            outs, sums = [], []
             for i in range(nb):
                 terms = []
                 for j in range(nb):
                     r = f"{q}fuse_layers.{i}.{j}."
-                    # path (i, j) reads branch j and is the only writer of grad(branch j) inside this output's section: one
-                    # lane per source branch, forward and backward (the sum itself is a serial record between the sections)
+                    # path (i, j) reads branch j and is the only writer of grad(branch j) among the paths: one lane per SOURCE
+                    # branch, forward and backward -- so the paths follow their branch on its lane without a join in between
                     self.cur_lane = j + 1 if (self.lanes and j != i) else 0
                     if j == i:
                         terms.append(Term(xs[j].t))
@@ -544,8 +545,20 @@ class Plan:
                                 v = self.cbr(v, f"{r}{k}.0", f"{r}{k}.1", co, 3, 2, True, tr)
                         terms.append(Term(v.t, v.bn))
                 self.cur_lane = 0
-                # reference sums in j order starting from j = 0
-                outs.append(self.combine(terms, True, size=(xs[i].t.H, xs[i].t.W), C=ch[i]))
+                if one_join:
+                    sums.append(terms)
+                else:
+                    # reference sums in j order starting from j = 0
+                    outs.append(self.combine(terms, True, size=(xs[i].t.H, xs[i].t.W), C=ch[i]))
+            if one_join:
+                # Every path of the module first (nb*(nb-1) of them, spread over the lanes), ONE join, then sum i on lane i+1:
+                # the next module's branch i follows it on the same lane, so a module costs one join (forward and backward)
+                # where "paths of output i -> join -> sum i" costs nb+1.
+                self.join()
+                for i in range(nb):
+                    self.cur_lane = i + 1
+                    outs.append(self.combine(sums[i], True, size=(xs[i].t.H, xs[i].t.W), C=ch[i]))
+                self.cur_lane = 0        # (no record is emitted here: the section stays open for the next module's branches)
             return outs
 
         ys = transition("transition1", [x], [256], Wd[:2])
@@ -568,6 +581,13 @@ class Plan:
         if not self.fuse_bn:
             o = self.combine([Term(o.t, o.bn)], True)
         return self.conv(o, p + "last_layer.3.weight", self.nc, 1, 1, True).t
+
+    def join(self):
+        """A lane-0 record that launches nothing: the interpreter joins the side lanes there.  Needed between two runs of lane
+        records when the second reads what SEVERAL lanes of the first wrote."""
+        self.cur_lane = 0
+        self.fwd.append((L.OP_JOIN, L.RawOp(0, 0, 0, 0)))
+        self.ops.append(("join",))
 
     # ------------------------------------------------------------------ backward program
     def _bn_backward(self, bn: BN, y: Ten, g_view: L.View, mask_mode, mask_view, dy_view: L.View, C, gm_view=None, gm_acc=0,
@@ -637,7 +657,9 @@ class Plan:
                 # parallel section the first serial record joins the side lanes before anything runs)
                 self._flush_wgrads()
             self.cur_lane = lane
-            if kind == "out":
+            if kind == "join":
+                self.bwd.append((L.OP_JOIN, L.RawOp(0, 0, 0, 0)))
+            elif kind == "out":
                 o = op[1]
                 g = self.grad_of(o)
                 r = L.RawOp(self.gout_buf, g.ptr, 0, 0)
