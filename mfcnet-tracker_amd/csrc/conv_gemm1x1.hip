@@ -27,6 +27,8 @@ struct GemmK {
     int nchunks, Yblocks, ntiles, tiles_per_block;
     int px_per_group, G, accumulate;
     int wt;                              // write-through output stores (common.h: large outputs only)
+    // data-gradient epilogue fusions (mfc_conv_desc.acc_src / bn_y; FUSE instantiation only), as in conv_igemm.hip
+    const char* acc_src; const char* bn_y; const float* bn_coef; const unsigned char* bn_bits; int bn_mode;
 };
 
 template <int CTRL> __device__ inline float g_dpp_add(float v) {
@@ -53,7 +55,8 @@ constexpr int G_OFF_BIAS = G_OFF_COEF + G_COEF_FLOATS * 4;       // float [Cout 
 constexpr int G_BIAS_FLOATS = 1024;
 constexpr int G_LDS = G_OFF_BIAS + G_BIAS_FLOATS * 4;            // = 160 KiB
 
-template <typename TE>
+// FUSE: the data-gradient epilogue fusions are compiled in (a separate instantiation: the plain one keeps its registers)
+template <typename TE, bool FUSE>
 __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)(smem + G_OFF_RED);
@@ -156,6 +159,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
         }
         __syncthreads();
     }
+    if constexpr (FUSE) {
+        if (p.bn_y) {      // (gemm1x1_launch: fits, and excludes in_coef)
+            for (int i = tid; i < p.G * 4 * p.Cout_p; i += 512) cfl[i] = p.bn_coef[i];
+            __syncthreads();
+        }
+    }
     auto transform = [&](int buf, int tt, int cc, int hh) {
         char* At = smem + G_OFF_A + buf * G_AH;
         const float* sc = cfl + (size_t)(((long)tt * G_BM) / p.px_per_group) * 2 * p.Cin_p;
@@ -223,19 +232,43 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
-            char* obase = p.out + (((size_t)t * G_BM + wm * 128 + (lane & 15)) * p.Cout_p + n0 + (lane >> 4) * 8) * 2;
-            // accumulate: the old values are requested four pixel tiles (8 stores) ahead, branch-free with a clamped address, so their
-            // latency is paid twice per unit and not once per store
-            uint4 oldv[4][2];
+            const size_t ooff = (((size_t)t * G_BM + wm * 128 + (lane & 15)) * p.Cout_p + n0 + (lane >> 4) * 8) * 2;
+            char* obase = p.out + ooff;
+            const char* abase = ((FUSE && p.acc_src) ? p.acc_src : (const char*)p.out) + ooff;      // where the running sum of an accumulating launch lives
+            const bool bnm = FUSE && p.bn_y != nullptr;                // fused BatchNorm / ReLU backward of the tensor this launch completes (wave-uniform)
+            // transposed-layout sums of the fused form: lane (row g = lane >> 4) owns channels n0 + pr*32 + 8g .. +7
+            // (the BatchNorm's coefficient block [G][4][Cout_p] sits in LDS: the region of the input-transform coefficients, which a
+            //  data gradient does not have)
+            float tsum[2][8], tsq[2][8];
+            int bco[2] = {0, 0};
+            if constexpr (FUSE) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { tsum[pr][e] = 0.f; tsq[pr][e] = 0.f; }
+                    bco[pr] = grp * 4 * p.Cout_p + min(n0 + pr * 32 + (lane >> 4) * 8, p.Cout_p - 8);
+                }
+            }
+            // accumulate: the old values (and, fused, the pre-BatchNorm tensor and the mask bytes) are requested four pixel tiles (8 stores)
+            // ahead, branch-free with a clamped address, so their latency is paid twice per unit and not once per store
+            constexpr int PF = FUSE ? 2 : 4;          // (the fused form prefetches three tensors: two tiles ahead keeps it out of scratch)
+            uint4 oldv[PF][2], pf_y[FUSE ? PF : 1][2]; unsigned pf_b[FUSE ? PF : 1][2];
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
-                if (p.accumulate && (mt & 3) == 0) {
+                if ((p.accumulate || bnm) && (mt & (PF - 1)) == 0) {
 #pragma unroll
-                    for (int m2 = 0; m2 < 4; ++m2)
+                    for (int m2 = 0; m2 < PF; ++m2)
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr) {
                             const bool vc0 = n0 + pr * 32 + (lane >> 4) * 8 < p.Cout_p;
-                            oldv[m2][pr] = *(const uint4*)(obase + (size_t)(mt + m2) * 16 * p.Cout_p * 2 + (vc0 ? pr * 64 : 0));
+                            const size_t off = (size_t)(mt + m2) * 16 * p.Cout_p * 2 + (vc0 ? pr * 64 : 0);
+                            oldv[m2][pr] = p.accumulate ? *(const uint4*)(abase + off) : make_uint4(0, 0, 0, 0);
+                            if constexpr (FUSE) {
+                                if (bnm) {
+                                    pf_y[m2][pr] = *(const uint4*)(p.bn_y + ooff + off);
+                                    if (p.bn_mode == 3) pf_b[m2][pr] = p.bn_bits[(ooff + off) >> 4];
+                                }
+                            }
                         }
                 }
                 float v[4][4];
@@ -243,18 +276,18 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v[nt][r] = acc[mt][nt][r] + bq[nt][r];
+                        if constexpr (FUSE) v[nt][r] = acc[mt][nt][r]; else v[nt][r] = acc[mt][nt][r] + bq[nt][r];          // (no bias with the fusions)
                         acc[mt][nt][r] = 0.f;
-                        ssum[nt][r] += v[nt][r]; ssq[nt][r] += v[nt][r] * v[nt][r];
+                        if constexpr (!FUSE) { ssum[nt][r] += v[nt][r]; ssq[nt][r] += v[nt][r] * v[nt][r]; }
                     }
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     // after the transpose lane (row g = lane>>4) owns channels n0 + pr*32 + 8g .. +7 of its pixel
                     char* oaddr = obase + (size_t)mt * 16 * p.Cout_p * 2 + pr * 64;
                     const bool vc = n0 + pr * 32 + (lane >> 4) * 8 < p.Cout_p;
-                    if (p.accumulate) {
+                    if (p.accumulate || bnm) {
                         // data gradient added to an existing one: in fp32 on the transposed layout (raw dwords transposed), rounded once
-                        const uint4 oldq = oldv[mt & 3][pr];
+                        const uint4 oldq = oldv[mt & (PF - 1)][pr];
                         unsigned t0[4], t1[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -266,6 +299,36 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
                         Gran<TE>::unpack(oldq, o8);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { w8[r] = __uint_as_float(t0[r]) + o8[r]; w8[4 + r] = __uint_as_float(t1[r]) + o8[4 + r]; }
+                        if constexpr (FUSE) {
+                            if (bnm) {
+                                // mask, store the MASKED gradient, keep sum g*m and sum g*m*yhat of the lane's 8 channels (what mfc_bnbwd_reduce
+                                // would sweep the tensor for again)
+                                float yv[8];
+                                Gran<TE>::unpack(pf_y[mt & (PF - 1)][pr], yv);
+                                const float* cf = cfl + bco[pr];
+                                const float4 m0 = *(const float4*)(cf + 2 * p.Cout_p), m1 = *(const float4*)(cf + 2 * p.Cout_p + 4);
+                                const float4 r0 = *(const float4*)(cf + 3 * p.Cout_p), r1 = *(const float4*)(cf + 3 * p.Cout_p + 4);
+                                const float bmean[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                                const float brstd[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                                unsigned mk = 0xffu;
+                                if (p.bn_mode == 2) {
+                                    const float4 s0 = *(const float4*)cf, s1 = *(const float4*)(cf + 4);
+                                    const float4 h0 = *(const float4*)(cf + p.Cout_p), h1 = *(const float4*)(cf + p.Cout_p + 4);
+                                    const float bsc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, bsh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                                    mk = 0;
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) mk |= ((yv[e] * bsc[e] + bsh[e]) > 0.f ? 1u : 0u) << e;
+                                } else if (p.bn_mode == 3) {
+                                    mk = pf_b[mt & (PF - 1)][pr];             // one byte per 8-channel granule (mfc_combine_fwd)
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const float gmv = ((mk >> e) & 1u) ? w8[e] : 0.f;
+                                    w8[e] = gmv;
+                                    if (vc) { tsum[pr][e] += gmv; tsq[pr][e] += gmv * ((yv[e] - bmean[e]) * brstd[e]); }
+                                }
+                            }
+                        }
                         if (vc) mfc_st16_if(oaddr, Gran<TE>::pack(w8), p.wt);
                     } else {
                         const unsigned p0 = pack2<TE>(v[2 * pr][0], v[2 * pr][1]), p1 = pack2<TE>(v[2 * pr][2], v[2 * pr][3]);
@@ -280,17 +343,32 @@ __global__ __launch_bounds__(512, 1) void conv_gemm1x1_kernel(GemmK p) {
             }
             if (p.out_stats) {
                 // lanes -> row sums -> this wave's LDS slots (only this wave touches them until the flush)
+                float* rw = red + (ybfast ? yb : 0) * G_RED1;
+                if (bnm) {
+                    if constexpr (FUSE) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                        for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float sa = g_row16_sum(ssum[nt][r]), sb = g_row16_sum(ssq[nt][r]);
-                        if ((lane & 15) == 0) {
-                            float* rw = red + (ybfast ? yb : 0) * G_RED1;
-                            rw[(wave * 2 + 0) * 64 + nt * 16 + cq + r] += sa;
-                            rw[(wave * 2 + 1) * 64 + nt * 16 + cq + r] += sb;
-                        }
+                            for (int e = 0; e < 8; ++e) {
+                                const float sa = g_row16_sum(tsum[pr][e]), sb = g_row16_sum(tsq[pr][e]);
+                                if ((lane & 15) == 0) {
+                                    rw[(wave * 2 + 0) * 64 + pr * 32 + (lane >> 4) * 8 + e] += sa;
+                                    rw[(wave * 2 + 1) * 64 + pr * 32 + (lane >> 4) * 8 + e] += sb;
+                                }
+                            }
                     }
+                } else if constexpr (!FUSE) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sa = g_row16_sum(ssum[nt][r]), sb = g_row16_sum(ssq[nt][r]);
+                            if ((lane & 15) == 0) {
+                                rw[(wave * 2 + 0) * 64 + nt * 16 + cq + r] += sa;
+                                rw[(wave * 2 + 1) * 64 + nt * 16 + cq + r] += sb;
+                            }
+                        }
+                }
                 red_live = true; red_grp = grp; red_yb = yb;
             }
         }
@@ -321,18 +399,34 @@ bool gemm1x1_eligible(const mfc_conv_desc* d) {
     return true;
 }
 
+// the acc_src / bn_y epilogue fusions: the BatchNorm's coefficient block is staged where the input-transform coefficients would be
+static bool gemm1x1_fusable(const mfc_conv_desc* d) {
+    if (d->in_coef || d->bias || d->images_per_group <= 0 || d->N % d->images_per_group) return false;
+    if (((long)d->images_per_group * d->Hout * d->Wout) % G_BM) return false;
+    return (long)(d->N / d->images_per_group) * 4 * d->Cout_p <= G_COEF_FLOATS;
+}
+
 int gemm1x1_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
     const int Cin_g = d->Cin_p / 8;
     out->KG = G_KG; out->nchunks = ceil_div(Cin_g, G_KG); out->NT16 = G_BN; out->Yblocks = ceil_div(d->Cout, G_BN);
     out->nslots = G_KG; out->TA = 1; out->TB = 1; out->TAS = 1; out->lds_bytes = G_LDS;
     out->bytes = (int64_t)out->nchunks * out->Yblocks * G_BBYTES;
     const int ntiles = (int)(((long)d->N * d->Hout * d->Wout) / G_BM);
-    out->MT = 8; out->TH = 1; out->TW = G_BM; out->grid = ntiles < 256 ? ntiles : 256; out->per_block = ceil_div(ntiles, out->grid); out->NW = 8; out->fa = 0;
+    out->MT = 8; out->TH = 1; out->TW = G_BM; out->grid = ntiles < 256 ? ntiles : 256; out->per_block = ceil_div(ntiles, out->grid); out->NW = 8;
+    out->fa = gemm1x1_fusable(d) ? 1 : 0;           // (the acc_src / bn_y epilogue fusions: the FUSE instantiation)
     return MFC_OK;
 }
 
 int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st) {
     if (!d->in || !d->wp || !d->out) return MFC_ERR_INVALID_ARG;
+    const bool fused = d->acc_src || d->bn_y;
+    if (fused) {
+        if (d->acc_src && !d->accumulate) return MFC_ERR_INVALID_ARG;
+        if (d->bn_y && (!d->bn_coef || !d->out_stats || (d->bn_mask_mode != 0 && d->bn_mask_mode != 2 && d->bn_mask_mode != 3) ||
+                        (d->bn_mask_mode == 3 && !d->bn_bits) || d->bias)) return MFC_ERR_INVALID_ARG;
+        if (d->out_stats && !d->bn_y) return MFC_ERR_UNSUPPORTED;          // (the FUSE instantiation keeps only the fused form's sums)
+        if (!gemm1x1_fusable(d)) return MFC_ERR_UNSUPPORTED;
+    }
     GemmK k;
     k.in = (const char*)d->in; k.wp = (const char*)d->wp; k.out = (char*)d->out; k.bias = d->bias; k.out_stats = d->out_stats;
     k.M = d->N * d->Hout * d->Wout; k.Cin_p = d->Cin_p; k.Cin_g = d->Cin_p / 8; k.Cout_p = d->Cout_p; k.Cout = d->Cout;
@@ -347,18 +441,23 @@ int gemm1x1_launch(const mfc_conv_desc* d, hipStream_t st) {
     k.accumulate = d->accumulate;
     k.wt = 0;          // (measured slower with write-through stores: 1.52 -> 1.58 ms per serial step; common.h)
     k.px_per_group = grouped ? d->images_per_group * d->Hout * d->Wout : k.M;
+    k.acc_src = (const char*)d->acc_src; k.bn_y = (const char*)d->bn_y; k.bn_coef = d->bn_coef; k.bn_bits = (const unsigned char*)d->bn_bits; k.bn_mode = d->bn_mask_mode;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_gemm1x1_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (g_mfc_prof_on == 1) {
         const double flops = 2.0 * k.M * (double)d->Cout * (double)d->Cin;
-        const double bytes = (double)k.M * (k.Cin_p + k.Cout_p) * 2.0;
-        mfc_prof_before(st, d->dtype == MFC_F16 ? "conv_gemm1x1_kernel<_Float16>" : "conv_gemm1x1_kernel<__bf16>", flops, bytes);
+        const double bytes = (double)k.M * (k.Cin_p + k.Cout_p * (1.0 + (d->accumulate ? 1.0 : 0.0) + (d->bn_y ? 1.0 : 0.0))) * 2.0;
+        mfc_prof_before(st, d->dtype == MFC_F16 ? (fused ? "conv_gemm1x1_kernel<_Float16, true>" : "conv_gemm1x1_kernel<_Float16, false>")
+                                                : (fused ? "conv_gemm1x1_kernel<__bf16, true>" : "conv_gemm1x1_kernel<__bf16, false>"), flops, bytes);
     }
-    MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL(conv_gemm1x1_kernel<T_>, dim3(grid), dim3(512), G_LDS, st, k));
+    if (fused) { MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL((conv_gemm1x1_kernel<T_, true>), dim3(grid), dim3(512), G_LDS, st, k)); }
+    else { MFC_TYPED16(d->dtype, T_, hipLaunchKernelGGL((conv_gemm1x1_kernel<T_, false>), dim3(grid), dim3(512), G_LDS, st, k)); }
     if (g_mfc_prof_on == 1) mfc_prof_after(st);
     MFC_CHECK_LAUNCH();
     return MFC_OK;

@@ -696,6 +696,8 @@ static int conv_setup(const mfc_conv_desc* d, ConvK& k, int& NT, int& MT, int& P
             double c = (double)ceil_div(n16n, cand[i]) * cand[i] * (1.0 + 0.5 / cand[i]);
             if (c < bestc - 1e-9) { bestc = c; ntn = cand[i]; }
         }
+        // (measured as well: last_layer[3]'s data gradient, 5 -> 480 channels, all stores -- blocked 4 tiles wide with the fused reduce it takes
+        //  ~0.33 ms longer and saves a 0.27 ms reduce pass)
         if (ntn != 2 && ntn != 4) want_fa = false;
     }
     if (!mfc_dtype_ok(d->dtype)) return MFC_ERR_INVALID_ARG;
@@ -958,7 +960,7 @@ extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
     if (!mfc_ptrs_ok(d->in, d->wp, d->out, d->bias, d->in_coef, d->out_stats, d->acc_src, d->bn_y, d->bn_coef, d->bn_bits)) return MFC_ERR_INVALID_ARG;
     if (ring_eligible(d)) return ring_launch(d, (hipStream_t)stream);
     const bool fused = d && (d->acc_src || d->bn_y);
-    if (d && gemm1x1_eligible(d)) return fused ? MFC_ERR_UNSUPPORTED : gemm1x1_launch(d, (hipStream_t)stream);
+    if (d && gemm1x1_eligible(d)) return gemm1x1_launch(d, (hipStream_t)stream);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;
     int rc = conv_setup(d, k, NT, MT, PM, lds, grid, NW);
     if (rc < 0) return rc;

@@ -176,7 +176,10 @@ FUSED_DG_CASES = [  # N, G, Cin, Cout, k, s, H, W, mask mode, accumulate from an
     (6, 3, 64, 32, 1, 1, 20, 28, 2, False), (3, 1, 32, 64, 3, 2, 23, 30, 2, True),
     # HRNet-W48's channel counts: 3- / 6-tile cout blocks, fused through the non-transposed epilogue (round 4)
     (6, 3, 48, 48, 3, 1, 24, 40, 3, True), (4, 2, 96, 96, 3, 1, 17, 21, 2, False), (3, 3, 192, 192, 3, 1, 15, 20, 3, True),
-    (3, 1, 384, 384, 3, 1, 8, 12, 0, False), (6, 3, 48, 96, 3, 2, 30, 40, 2, False), (2, 2, 96, 192, 3, 2, 15, 21, 3, True)]
+    (3, 1, 384, 384, 3, 1, 8, 12, 0, False), (6, 3, 48, 96, 3, 2, 30, 40, 2, False), (2, 2, 96, 192, 3, 2, 15, 21, 3, True),
+    # wide 1x1 data gradients (layer1's 64 -> 256 bottleneck convolutions, hrnet.py:77-111): the plain-GEMM kernel's fused epilogue
+    (6, 3, 256, 64, 1, 1, 16, 24, 3, True), (6, 3, 256, 64, 1, 1, 16, 24, 0, False), (3, 3, 256, 128, 1, 1, 16, 16, 2, False),
+    (2, 1, 512, 64, 1, 1, 16, 16, 3, True)]
 
 
 @pytest.mark.parametrize("merged", [False, True], ids=["", "s2-one-launch"])
@@ -222,23 +225,24 @@ def test_dgrad_fused_bn_backward_reduce(dt16, M, case, merged):
     bstats = torch.zeros(L.STAT_REPLICAS, G, 2, Cin, dtype=torch.float64, device="cuda")
     coef_d = coef.cuda()
     Ho, Wo, pad = yo.shape[2], yo.shape[3], k // 2
+    Cop = -(-Cout // 8) * 8                   # (channel pitch of the gradient the launch reads)
     keep, launched = [], 0
     classes = [(0, 0)] if (s == 1 or merged) else [(a, b) for a in range(2) for b in range(2)]
     for (ph, pw) in classes:
         if merged:       # MFC_CONV_S2_CLASSES: the four parity classes in one launch
-            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, (H + 1) // 2, (W + 1) // 2,
+            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cop, Cout, H, W, Cin, Cin, (H + 1) // 2, (W + 1) // 2,
                            2, 2, 0, 0, 1, 2, 2, 0, 0, 0, ipg, 1 if acc else 0, 0, 0)
             d.flags = L.CONV_S2_CLASSES
             mode_s, cls = "dgrad_s2_all", (0, 0)
         elif s == 1:
-            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, H, W,
+            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cop, Cout, H, W, Cin, Cin, H, W,
                            k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, ipg, 1 if acc else 0, 0, 0)
             mode_s, cls = "dgrad", (0, 0)
         else:
             ta, _, dh0 = ops.s2_class(k, pad, ph)
             tb, _, dw0 = ops.s2_class(k, pad, pw)
             Hl, Wl = (H - ph + 1) // 2, (W - pw + 1) // 2
-            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, Hl, Wl,
+            d = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), ops.dt_of(dx), N, Ho, Wo, Cop, Cout, H, W, Cin, Cin, Hl, Wl,
                            ta, tb, dh0, dw0, 1, 2, 2, ph, pw, 0, ipg, 1 if acc else 0, 0, 0)
             mode_s, cls = "dgrad_s2", (ph, pw)
         d.flags |= L.CONV_WANT_FA
@@ -258,7 +262,7 @@ def test_dgrad_fused_bn_backward_reduce(dt16, M, case, merged):
     assert relerr(st[:, 0], s1_ref) < 5 * TOL[dt16]
     assert relerr(st[:, 1], s2_ref) < 5 * TOL[dt16]
     # a launch that cannot take the fusion must refuse it rather than drop it
-    d2 = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), L.F32, N, Ho, Wo, Cout, Cout, H, W, Cin, Cin, H, W,
+    d2 = L.ConvDesc(dyd.data_ptr(), 0, dx.data_ptr(), 0, 0, bstats.data_ptr(), L.F32, N, Ho, Wo, Cop, Cout, H, W, Cin, Cin, H, W,
                     k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, ipg, 0, 0, 0)
     d2.bn_y, d2.bn_coef, d2.wp = yd.data_ptr(), coef_d.data_ptr(), keep[0].data_ptr()
     assert L.lib.mfc_conv2d_fwd(C.byref(d2), L.stream_ptr()) < 0

@@ -42,3 +42,15 @@ for t, d in ev:
     hist[cur] += t - last; last = t; cur += d
 tot = sum(hist.values())
 print("kernels running concurrently: " + ", ".join(f"{k}: {100 * v / tot:.1f}%" for k, v in sorted(hist.items())))
+# per stream: busy fraction per millisecond of the step (which stream the tail of the step is waiting for)
+nb = int((t1 - t0) / 1e6) + 1
+print("busy % per ms of the step, by stream (rows) -- columns are ms 0.." + str(nb - 1))
+for key, ks in sorted(by.items(), key=lambda kv: kv[1][0][0]):
+    occ = [0.0] * nb
+    for s, e, _ in ks:
+        a_, b_ = (s - t0) / 1e6, (e - t0) / 1e6
+        i = int(a_)
+        while i < nb and i < b_:
+            occ[i] += min(b_, i + 1) - max(a_, i)
+            i += 1
+    print(f"  stream {key[1]:3d}: " + " ".join(f"{int(100 * min(o, 1.0)):3d}" for o in occ))
