@@ -116,6 +116,20 @@ def synth(B, T, H, W, nc, seed, device, depth=False, optflow=False):
     return frames, mask, dm, fl
 
 
+def code_hash():
+    """sha1 over what decides the launches and their traffic (kernel sources, headers, the planner): a committed PMC table is only as good as the
+    code it was taken on -- tools/summarize_profile.py stores this hash in the table, bench.py says whether it still matches."""
+    import glob, hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "mfcnet-tracker_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mfcnet-tracker_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.join(ROOT, "mfcnet-tracker_amd", "mfcnet_amd", "plan.py")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/profile_round.sh: separate rocprofv3 --pmc runs of
     this command, FETCH_SIZE doubled per MI355X_MICROARCH.md; condensed by tools/summarize_profile.py).  bench.py cannot
@@ -128,7 +142,10 @@ def pmc_traffic(kernel, args):
     path = found[-1]
     with open(path) as f:
         doc = json.load(f)
-    src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial`)"
+    fresh = doc.get("code_hash") == code_hash()
+    src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --serial`; " + \
+          ("taken on this code: kernel sources, headers and planner hash " + str(doc.get("code_hash")) if fresh else
+           "STALE: taken on other kernel / planner sources than the ones running (hash " + str(doc.get("code_hash")) + " vs " + code_hash() + ")") + ")"
     if kernel is None:                                        # whole step: counter bytes of every kernel of one training step
         return (doc.get("step") or {}).get("hbm_bytes_per_step"), src
     ks = doc["kernels"]

@@ -243,3 +243,23 @@ def test_product_key_hash_generator_equals_the_oracles():
     assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
     fill_hashed(s)
     assert torch.equal(s.state_dict()["conv1.weight"], b["conv1.weight"])
+
+
+def test_committed_pmc_table_says_which_code_it_was_taken_on(tmp_path, monkeypatch):
+    """bench.py prices `roofline.traffic` / `step.counter_gb` from the newest committed PMC table: the table carries a hash of the kernel
+    sources, headers and planner it was taken on, and the bench line says so -- or says STALE when the sources have moved on."""
+    import argparse
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(width=32, dtype="bf16", batch=8, frames=3, height=480, width_px=640, depth=False, optflow=False, basic=False,
+                              single=False, fwd_only=False)
+    val, src = bench.pmc_traffic(None, args)
+    assert val and val > 5e10 and "profiles/r" in src
+    import glob
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_w32_pmc_traffic.json")))[-1]
+    doc = json.load(open(newest))
+    assert ("taken on this code" in src) == (doc.get("code_hash") == bench.code_hash())
+    assert ("STALE" in src) != ("taken on this code" in src)
+    monkeypatch.setattr(bench, "code_hash", lambda: "0" * 16)
+    assert "STALE" in bench.pmc_traffic(None, args)[1]

@@ -155,6 +155,12 @@ def main():
                 step_bytes += (2.0 * f_kb + w_kb) * 1024.0 * calls
         out["step"] = {"steps_in_run": nsteps, "hbm_bytes_per_step": round(step_bytes / nsteps),
                        "note": "counter bytes of every kernel of the run except model set-up (copies, fills, weight packing), divided by the steps of the run"}
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        try:
+            from bench import code_hash                      # (what the table was taken on: bench.py marks it stale when the sources move on)
+            out["code_hash"] = code_hash()
+        except Exception as e:                                # noqa: BLE001
+            out["code_hash"] = None
         with open(os.path.join(outdir, f"{tag}_pmc_traffic.json"), "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
         for n in sorted(out["kernels"], key=lambda k: -out["kernels"][k]["hbm_bytes_per_launch"] * out["kernels"][k]["dispatches"])[:8]:
