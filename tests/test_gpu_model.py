@@ -579,6 +579,32 @@ def test_lanes_do_not_change_results(mfc):
     assert torch.equal(y0, y1) and torch.equal(g0, g1)
 
 
+def test_one_join_per_module_is_the_same_network(mfc):
+    """Round 4: a HighResolutionModule's fuse stage is emitted as "every path, ONE join (a no-launch MFC_OP_JOIN record), then sum i on lane i + 1"
+    instead of "paths of output i -> join -> sum i" (hrnet.py:238-262).  Same records, other order and lanes: the logits are the same bit for
+    bit; the gradients agree to rounding (the order decides which data-gradient launch completes a tensor and so takes the fused
+    BatchNorm-backward epilogue, whose sums are taken before the bf16 rounding of the stored gradient)."""
+    from mfcnet_amd import _lib as L
+    cfg, z = load_case("large_rgb_train")
+    frames, flows, depths, mask = case_inputs(cfg)
+    res = []
+    for one in (True, False):
+        m = build(mfc, cfg)
+        m.fuse_one_join = one
+        set_mode(m, "train")
+        y = m(dev(frames))
+        loss, _ = mfc.mfc_loss(y, mask.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        plan = next(iter(m._plans.values()))
+        njoin = sum(1 for op in plan.fwd_prog if op.kind == L.OP_JOIN)
+        assert njoin == (8 if one else 0)                 # stage2: 1 module, stage3: 4, stage4: 3 (hrnet.py:297-333)
+        res.append((y.detach().cpu(), m._G.detach().cpu().clone(), float(loss)))
+    (y0, g0, l0), (y1, g1, l1) = res
+    assert torch.equal(y0, y1) and l0 == l1
+    assert float((g0 - g1).abs().max()) <= 2e-3 * float(g1.abs().max())
+
+
 def test_hoisted_eval_bn_finalize_is_bit_identical(mfc):
     """Eval-mode BatchNorm finalizes run as ONE table launch in front of the program (mfc_bn_finalize_batch); the logits are
     those of the per-record form -- bit for bit in full eval mode; with only the base model frozen (engine.py:25-26) up to
