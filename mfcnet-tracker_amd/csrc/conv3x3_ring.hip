@@ -236,7 +236,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
     }
     const bool bnm = FUSE && p.bn_y != nullptr;
     if constexpr (FUSE) {
-        if (bnm) for (int i = tid; i < p.G * 4 * C; i += 256) bncl[i] = p.bn_coef[i];
+        // rows 0 / 1: scale / shift (mask of bn_mode 2); row 2 is stored as -mean * rstd next to row 3 = rstd: yhat = y * rstd + row2, one fma per element
+        if (bnm) for (int i = tid; i < p.G * 4 * C; i += 256) {
+            const int r = (i / C) & 3;
+            bncl[i] = r == 2 ? -p.bn_coef[i] * p.bn_coef[i + C] : p.bn_coef[i];
+        }
     }
 
     // ---------------- in-LDS fix-up of a landed slot: zero what lies outside the image; the producer's BatchNorm + ReLU ----------------
@@ -467,14 +471,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(RingK p) {
                             } else if (p.bn_mode == 3) {
                                 mk = pf_bits[mt];                 // one byte per 8-channel granule (mfc_combine_fwd)
                             }
+                            if (!vpx) mk = 0;                     // (pixels outside the image: masked out, so the sums below need no select; their y is finite, clamped address)
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 const float gmv = ((mk >> e) & 1u) ? w[e] : 0.f;
                                 w[e] = gmv;
-                                if (vpx) {
-                                    ssum[e >> 2][e & 3] += gmv;
-                                    ssq[e >> 2][e & 3] += gmv * ((yv[e] - cf[2 * C + e]) * cf[3 * C + e]);
-                                }
+                                ssum[e >> 2][e & 3] += gmv;
+                                ssq[e >> 2][e & 3] += gmv * (yv[e] * cf[3 * C + e] + cf[2 * C + e]);
                             }
                         }
                         if (vpx) mfc_st16_if((tbase + off), Gran<T>::pack(w), p.wt);
