@@ -310,7 +310,12 @@ def main():
                 opts.is_high_priority_stream = True
             except Exception:
                 opts = None
-            dist.init_process_group("nccl", device_id=device, pg_options=opts)
+            try:
+                dist.init_process_group("nccl", device_id=device, pg_options=opts)
+            except (TypeError, ValueError):          # (an older / newer torch that does not take these keywords: plain initialisation)
+                if dist.is_initialized():
+                    raise
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(args.backend)
         if dist.get_world_size() != args.gpus:
