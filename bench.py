@@ -394,7 +394,7 @@ def main():
                       ("MFC_WGRAD_MAXPX", 21), ("MFC_CONV_NW8", 19), ("MFC_CONV_FILL_PCT", 18), ("MFC_CONV_GRID", 4),
                       ("MFC_ASYNC_PRIO", 16), ("MFC_SKIP_KINDS", 15), ("MFC_ASYNC_ON_LANE", 13), ("MFC_OWN_MAIN", 14),
                       ("MFC_LANE_STREAMS", 12), ("MFC_LANES", 9), ("MFC_ASYNC_STREAMS", 10), ("MFC_WGRAD_DMA", 29), ("MFC_CONV_MT", 2), ("MFC_CONV_LDS_KB", 6),
-                      ("MFC_CONV_RING", 30), ("MFC_RING_WGS", 33), ("MFC_WGRAD_XF8", 38), ("MFC_APPLYFIN_BLOCKS", 39), ("MFC_BNRED_THREADS", 41), ("MFC_BNRED_MINPX", 42), ("MFC_WGRAD_DMA_S2", 46), ("MFC_WGRAD_DMA48", 47), ("MFC_WGRAD_DMA48_X2", 48), ("MFC_WT_MIN_MB", 54), ("MFC_CONV_NW8_FUSED", 55), ("MFC_LANE4_FWD", 56)):
+                      ("MFC_CONV_RING", 30), ("MFC_RING_WGS", 33), ("MFC_WGRAD_XF8", 38), ("MFC_APPLYFIN_BLOCKS", 39), ("MFC_BNRED_THREADS", 41), ("MFC_BNRED_MINPX", 42), ("MFC_WGRAD_DMA_S2", 46), ("MFC_WGRAD_DMA48", 47), ("MFC_WGRAD_DMA48_X2", 48), ("MFC_WT_MIN_MB", 54), ("MFC_CONV_NW8_FUSED", 55), ("MFC_LANE4_FWD", 56), ("MFC_RING_C64_UNFUSED_KPX", 57)):
         if os.environ.get(env):
             L.lib.mfc_set_flag(flag, int(os.environ[env]))
     if args.serial:

@@ -28,6 +28,7 @@ int g_conv_ring = 1;
 int g_ring_ablate = 0;
 int g_ring_stagger = 0;
 int g_ring_wgs = 2;                       // workgroups per CU the grid is sized for (tuning: mfc_set_flag(33, n))
+long g_ring_c64_unfused_px = 300000;       // pixels from which a 64-channel data gradient prefers the unfused ring launch (tuning: mfc_set_flag(57, px / 1000))
 int g_ring_grid = 0;                      // > 0: workgroups per launch (tuning / probes: mfc_set_flag(52, n)); 0 = 256 * g_ring_wgs
 
 struct RingK {
@@ -551,7 +552,11 @@ bool ring_eligible(const mfc_conv_desc* d) {
     if (d->bias || d->TH > 0 || d->TW > 0) return false;
     // (64 channels with the data-gradient epilogue fusions: 144 VGPRs of resident weights + the fused epilogue's operands do not fit in
     //  256 registers -- hipcc spills 200 of them; those launches stay on conv_igemm.hip)
-    if (d->Cin == 64 && ((d->flags & MFC_CONV_WANT_FA) || d->acc_src || d->bn_y || d->accumulate)) return false;
+    if (d->Cin == 64 && (d->acc_src || d->bn_y || d->accumulate)) return false;
+    // a 64-channel data gradient that ASKS for a fusable launch (MFC_CONV_WANT_FA) gets conv_igemm's -- except on large images, where the plain ring launch
+    // plus a separate reduce pass is faster than conv_igemm's fused one (layer1's conv2 at 120x160, N = 24: 56 + 30 us against 119 us); mfc_conv2d_layout
+    // then reports fa = 0 and the planner keeps the reduce record
+    if (d->Cin == 64 && (d->flags & MFC_CONV_WANT_FA) && (long)d->N * d->Hin * d->Win < g_ring_c64_unfused_px) return false;
     if (d->N <= 0 || d->images_per_group <= 0 || d->N % d->images_per_group || d->N / d->images_per_group > 8) return false;
     if (d->Hin < 2 || d->Win < 2) return false;
     if ((double)d->Hin * d->Win * d->Cin * 2.0 >= 2.0e9) return false;          // 32-bit lane offsets inside one image
@@ -605,7 +610,7 @@ int ring_layout(const mfc_conv_desc* d, mfc_conv_layout* out) {
     out->TA = 3; out->TB = 3; out->TAS = 3; out->lds_bytes = (int32_t)lds;
     out->bytes = (int64_t)9 * (C / 8) * C * 16;
     out->MT = MT; out->TH = (C == 32 ? 4 : 2) * MT; out->TW = 16; out->grid = grid; out->per_block = k.per_block; out->NW = 4;
-    out->fa = 1;
+    out->fa = (C == 32) ? 1 : 0;            // (the 64-channel fused variants spill: no fusions offered)
     return MFC_OK;
 }
 

@@ -44,6 +44,7 @@ int mfc_conv_set_fill_pct(int v);
 int mfc_conv_set_nw8(int v);
 int mfc_set_lane4_fwd(int v);
 extern int g_conv_wres, g_conv_gemm, g_conv_gemm_minc, g_wgrad_gemm, g_wgrad_gemm_minc, g_bnred_blocks, g_wgrad_dma, g_conv_ring, g_ring_ablate, g_ring_wgs, g_ring_stagger, g_wgrad_dma_xf8, g_applyfin_blocks, g_ew_ablate, g_bnred_threads, g_bnred_minpx, g_wgrad_dma_s2, g_wgrad_dma48, g_wgrad_dma48_x2, g_ring_grid, g_conv_nw8_fused;
+extern long g_ring_c64_unfused_px;
 int mfc_ring_set_mt(int v);
 extern "C" int mfc_set_flag(int id, int value) {
     if (id == 1) { g_wgrad_use_tr = value; return 0; }
@@ -90,6 +91,7 @@ extern "C" int mfc_set_flag(int id, int value) {
     if (id == 52) { g_ring_grid = value > 0 ? value : 0; return 0; }
     if (id == 53) { g_mfc_validate_ptrs = value ? 1 : 0; return 0; }
     if (id == 56) return mfc_set_lane4_fwd(value);
+    if (id == 57) { g_ring_c64_unfused_px = (long)value * 1000; return 0; }
     if (id == 55) { g_conv_nw8_fused = value; return 0; }
     if (id == 54) { g_mfc_wt_min_mb = value > 0 ? value : 0; return 0; }
     if (id == 11) { g_wgrad_blocks = value > 0 ? value : 256; return 0; }
