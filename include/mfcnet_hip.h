@@ -144,6 +144,11 @@ typedef struct {
  * TA = TB = 2, kh_step = kw_step = -2 and (kh0, kw0) = (1 + ph, 1 + pw) -- taps that fall outside the filter are written as zeros.  The
  * epilogue options (accumulate, acc_src, bn_y, out_stats) apply to every class. */
 #define MFC_CONV_S2_CLASSES 2
+/* flags bit 2 (round 4): the caller guarantees that no launch of this descriptor accumulates (accumulate = 0, acc_src = NULL) -- the planner sets it on data
+ * gradients whose result has exactly one producer (the input of the forward convolution is a never-materialised conv -> BN -> ReLU tensor).  It lets
+ * mfc_conv2d_layout choose launches that have no accumulating form (the 64-channel ring launch on large images); a launch that accumulates anyway is
+ * refused with MFC_ERR_INVALID_ARG.  Like bit 0 it must be set BEFORE mfc_conv2d_layout / packing: the packed weight image follows the launch. */
+#define MFC_CONV_NEVER_ACC 4
 int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream);
 /* The packed weight image a launch of `d` reads is laid out [TA/TAS][nchunks][Yblocks][nslots][NT16][granule]
  * (slot = (row-in-group, tap column, granule-in-chunk)): the weights of one (tap-row group, channel chunk, cout block) stage are one contiguous block that is DMA-copied

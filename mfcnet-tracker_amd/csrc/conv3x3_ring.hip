@@ -552,11 +552,13 @@ bool ring_eligible(const mfc_conv_desc* d) {
     if (d->bias || d->TH > 0 || d->TW > 0) return false;
     // (64 channels with the data-gradient epilogue fusions: 144 VGPRs of resident weights + the fused epilogue's operands do not fit in
     //  256 registers -- hipcc spills 200 of them; those launches stay on conv_igemm.hip)
-    if (d->Cin == 64 && (d->acc_src || d->bn_y || d->accumulate)) return false;
+    if (d->Cin == 64 && !(d->flags & MFC_CONV_NEVER_ACC) && (d->acc_src || d->bn_y || d->accumulate)) return false;
     // a 64-channel data gradient that ASKS for a fusable launch (MFC_CONV_WANT_FA) gets conv_igemm's -- except on large images, where the plain ring launch
     // plus a separate reduce pass is faster than conv_igemm's fused one (layer1's conv2 at 120x160, N = 24: 56 + 30 us against 119 us); mfc_conv2d_layout
     // then reports fa = 0 and the planner keeps the reduce record
-    if (d->Cin == 64 && (d->flags & MFC_CONV_WANT_FA) && (long)d->N * d->Hin * d->Win < g_ring_c64_unfused_px) return false;
+    // (only for descriptors that promise never to accumulate, MFC_CONV_NEVER_ACC: the kernel choice -- and with it the packed weight layout -- must not
+    //  depend on a field the planner fills in later)
+    if (d->Cin == 64 && (d->flags & MFC_CONV_WANT_FA) && (!(d->flags & MFC_CONV_NEVER_ACC) || (long)d->N * d->Hin * d->Win < g_ring_c64_unfused_px)) return false;
     if (d->N <= 0 || d->images_per_group <= 0 || d->N % d->images_per_group || d->N / d->images_per_group > 8) return false;
     if (d->Hin < 2 || d->Win < 2) return false;
     if ((double)d->Hin * d->Win * d->Cin * 2.0 >= 2.0e9) return false;          // 32-bit lane offsets inside one image
@@ -637,6 +639,8 @@ int ring_launch(const mfc_conv_desc* d, hipStream_t st) {
     const int rc = ring_setup(d, k, lds, grid, MT);
     if (rc < 0) return rc;
     const bool fused = d->acc_src || d->bn_y || d->accumulate;
+    if ((d->flags & MFC_CONV_NEVER_ACC) && (d->accumulate || d->acc_src)) return MFC_ERR_INVALID_ARG;          // (the promise the layout was chosen on)
+    if (d->Cin == 64 && fused) return MFC_ERR_UNSUPPORTED;                                                      // (no fused 64-channel form: mfc_conv2d_layout reported fa = 0)
     if (d->acc_src && !d->accumulate) return MFC_ERR_INVALID_ARG;
     if (d->bn_y && (!d->bn_coef || !d->out_stats || (d->bn_mask_mode != 0 && d->bn_mask_mode != 2 && d->bn_mask_mode != 3) ||
                     (d->bn_mask_mode == 3 && !d->bn_bits))) return MFC_ERR_INVALID_ARG;

@@ -959,6 +959,7 @@ extern "C" int mfc_conv2d_fwd(const mfc_conv_desc* d, void* stream) {
     if (!d) return MFC_ERR_INVALID_ARG;
     if (!mfc_ptrs_ok(d->in, d->wp, d->out, d->bias, d->in_coef, d->out_stats, d->acc_src, d->bn_y, d->bn_coef, d->bn_bits)) return MFC_ERR_INVALID_ARG;
     if (ring_eligible(d)) return ring_launch(d, (hipStream_t)stream);
+    if ((d->flags & MFC_CONV_NEVER_ACC) && (d->accumulate || d->acc_src)) return MFC_ERR_INVALID_ARG;
     const bool fused = d && (d->acc_src || d->bn_y);
     if (d && gemm1x1_eligible(d)) return gemm1x1_launch(d, (hipStream_t)stream);
     ConvK k; int NT, MT, PM, grid, NW; size_t lds;

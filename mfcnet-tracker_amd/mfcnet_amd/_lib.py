@@ -36,6 +36,7 @@ OP_WSNORM, OP_GNFIN, OP_UPNEAR = 19, 20, 21
 OP_GNBWD_FIN, OP_WSBWD, OP_UPNEAR_BWD, OP_JOIN = 22, 23, 24, 25
 WGRAD_MAXBATCH = 8
 CONV_WANT_FA = 1
+CONV_NEVER_ACC = 4
 CONV_S2_CLASSES = 2      # mfc_conv_desc.flags: data gradient of a 3x3 / stride-2 convolution, all four output parity classes in one launch
 RUN_DEFER_JOIN = 1
 

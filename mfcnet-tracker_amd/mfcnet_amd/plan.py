@@ -252,6 +252,8 @@ class Plan:
                     d = L.ConvDesc(16, 0, 16, 0, 0, 0, self.dtype, y.N, y.H, y.W, y.Cp, cout, xt.H, xt.W, xt.Cp, xt.C, xt.H, xt.W,
                                    k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0, 0, y.ipg, 0, 0, 0)
                     d.flags = L.CONV_WANT_FA if self.fuse_bnred else 0      # (before packing: the weight image follows the geometry)
+                    if in_coef and k == 3:     # x is the never-materialised conv -> BN -> ReLU tensor inside a residual block (hrnet.py:62-69, :99-106):
+                        d.flags |= L.CONV_NEVER_ACC          # one consumer, so this launch is the only writer of its gradient (checked when the backward is emitted)
                     self._pack(d, src, cout, cin, k, TA=k, TB=k, kh0=k - 1, kh_step=-1, kw0=k - 1, kw_step=-1, mode=1)
                     ci.dgrad.append(d)
                 elif stride == 2 and k == 3 and pad == 1 and self.merge_s2:
@@ -792,6 +794,8 @@ class Plan:
                             self._materialise_grad_src(xt)
                     acc = 1 if (xt.grad_init or src is not None) else 0
                     for d in ci.dgrad:
+                        if (d.flags & L.CONV_NEVER_ACC) and (acc or src is not None):
+                            raise L.MfcError(f"{ci.wname}: a data gradient planned as the only writer of its result would have to accumulate")
                         d.inp, d.out, d.accumulate = dy.ptr, dx.ptr, acc
                         d.acc_src = src.ptr if src is not None else 0
                         self.bwd.append((L.OP_CONV, d))

@@ -263,3 +263,36 @@ def test_committed_pmc_table_says_which_code_it_was_taken_on(tmp_path, monkeypat
     assert ("STALE" in src) != ("taken on this code" in src)
     monkeypatch.setattr(bench, "code_hash", lambda: "0" * 16)
     assert "STALE" in bench.pmc_traffic(None, args)[1]
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (960, 1280)], ids=["480x640", "960x1280-c64-branch-over-the-ring-threshold"])
+def test_every_planned_launch_reads_the_weight_image_that_was_packed_for_it(H, W):
+    """The packed weight image of a convolution launch follows the launch geometry mfc_conv2d_layout chose when the plan was built; the planner fills
+    `accumulate` / `acc_src` / `bn_y` in later.  Whatever those fields become, the launch the library picks for the FINAL descriptor must still be the
+    one the image was packed for (a kernel choice that depended on a late field would silently read another kernel's layout): checked for every
+    convolution record of the forward and backward programs on a dry plan -- also at a size where the 64-channel branch is past the pixel count
+    from which data gradients that promise never to accumulate (MFC_CONV_NEVER_ACC) take the unfused ring launch."""
+    import mfcnet_amd as mfc
+    from mfcnet_amd import _lib as L
+    from mfcnet_amd.plan import Plan
+    m = mfc.HRNetMultiLarge(num_classes=5, num_frames=3, pretrained=False, width=32, compute_dtype="bf16").train()
+    pl = Plan(m, 8, H, W, False, False, True, True, True, torch.device("cpu"), dry=True)
+    jobs = {}
+    for j in pl.pack_jobs:
+        jobs.setdefault(j["dst"], j)
+    keys = ("KG", "nchunks", "NT16", "Yblocks", "nslots", "TAS")
+    n = ring64 = 0
+    for rec in list(pl.fwd) + list(pl.bwd):
+        if rec[0] != L.OP_CONV:
+            continue
+        d = rec[1]
+        lay = L.conv_layout(d)
+        job = jobs[d.wp]
+        now = L.pack_job_fields(lay)
+        assert all(job[k] == now[k] for k in keys), (d.Cin, d.Cout, d.TA, d.Hin, d.accumulate, bool(d.acc_src), bool(d.bn_y), {k: (job[k], now[k]) for k in keys})
+        n += 1
+        if d.Cin == 64 and d.Cout == 64 and d.TA == 3 and (d.flags & L.CONV_NEVER_ACC) and lay.fa == 0:
+            assert not d.accumulate and not d.acc_src and not d.bn_y
+            ring64 += 1
+    assert n > 500
+    assert ring64 == (4 if H == 480 else 4 + 32)          # layer1's four conv2 data gradients; at 960x1280 also the 32 of the 64-channel branch
