@@ -46,7 +46,7 @@ extern "C" {
  *  54  write-through (sc1) 16-byte output stores from this many MB of output per launch (12; 0 = plain stores everywhere): mfcnet-tracker_amd/csrc/common.h, mfc_st16
  *  55  conv: score weight (%) of the 8-wave geometries for launches that want the fused data-gradient epilogue (0: 4-wave forms; -1 = switch 19)
  *  56  lanes: in a program without detached records (the forward pass) lane 4 runs on the detached stream's hardware queue (1)
- *  57  ring kernel: thousands of pixels (N*H*W) from which a 64-channel data gradient takes the unfused ring launch + a reduce pass (300) */
+ *  57  ring kernel: thousands of pixels (N*H*W) from which a 64-channel data gradient takes the unfused ring launch + a reduce pass (100) */
 int mfc_set_flag(int id, int value);
 #ifdef __cplusplus
 }

@@ -28,7 +28,8 @@ int g_conv_ring = 1;
 int g_ring_ablate = 0;
 int g_ring_stagger = 0;
 int g_ring_wgs = 2;                       // workgroups per CU the grid is sized for (tuning: mfc_set_flag(33, n))
-long g_ring_c64_unfused_px = 300000;       // pixels from which a 64-channel data gradient prefers the unfused ring launch (tuning: mfc_set_flag(57, px / 1000))
+long g_ring_c64_unfused_px = 100000;       // pixels from which a 64-channel data gradient prefers the unfused ring launch (tuning: mfc_set_flag(57, px / 1000)).  Measured at N = 24:
+                                          // 120x160 (layer1) -0.1 ms per step, 60x80 (the 64-channel branch's 32 conv2 gradients) another -0.4 ms (34.5 -> 34.1)
 int g_ring_grid = 0;                      // > 0: workgroups per launch (tuning / probes: mfc_set_flag(52, n)); 0 = 256 * g_ring_wgs
 
 struct RingK {
@@ -554,7 +555,8 @@ bool ring_eligible(const mfc_conv_desc* d) {
     //  256 registers -- hipcc spills 200 of them; those launches stay on conv_igemm.hip)
     if (d->Cin == 64 && !(d->flags & MFC_CONV_NEVER_ACC) && (d->acc_src || d->bn_y || d->accumulate)) return false;
     // a 64-channel data gradient that ASKS for a fusable launch (MFC_CONV_WANT_FA) gets conv_igemm's -- except on large images, where the plain ring launch
-    // plus a separate reduce pass is faster than conv_igemm's fused one (layer1's conv2 at 120x160, N = 24: 56 + 30 us against 119 us); mfc_conv2d_layout
+    // plus a separate reduce pass is faster than conv_igemm's fused one (layer1's conv2 at 120x160, N = 24: 56 + 30 us against 119 us; at 60x80 17 + 12 against
+    // 31, and the ring launches share the chip better with the other lanes); mfc_conv2d_layout
     // then reports fa = 0 and the planner keeps the reduce record
     // (only for descriptors that promise never to accumulate, MFC_CONV_NEVER_ACC: the kernel choice -- and with it the packed weight layout -- must not
     //  depend on a field the planner fills in later)

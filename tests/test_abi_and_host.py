@@ -266,7 +266,7 @@ def test_committed_pmc_table_says_which_code_it_was_taken_on(tmp_path, monkeypat
 
 
 @pytest.mark.parametrize("H,W,width", [(480, 640, 32), (960, 1280, 32), (480, 640, 48), (720, 960, 48)],
-                         ids=["w32-480x640", "w32-960x1280-c64-branch-over-the-ring-threshold", "w48-480x640", "w48-720x960"])
+                         ids=["w32-480x640", "w32-960x1280", "w48-480x640", "w48-720x960"])
 def test_every_planned_launch_reads_the_weight_image_that_was_packed_for_it(H, W, width):
     """The packed weight image of a convolution launch follows the launch geometry mfc_conv2d_layout chose when the plan was built; the planner fills
     `accumulate` / `acc_src` / `bn_y` in later.  Whatever those fields become, the launch the library picks for the FINAL descriptor must still be the
@@ -296,5 +296,5 @@ def test_every_planned_launch_reads_the_weight_image_that_was_packed_for_it(H, W
             assert not d.accumulate and not d.acc_src and not d.bn_y
             ring64 += 1
     assert n > 500
-    # layer1's four conv2 data gradients (every width); W32 at 960x1280 also the 32 conv2's of its 64-channel branch
-    assert ring64 == (4 + 32 if (width == 32 and H == 960) else 4)
+    # layer1's four conv2 data gradients (every width); W32 also the 32 conv2's of its 64-channel branch (N * H * W >= 100 000 pixels at both sizes)
+    assert ring64 == (4 + 32 if width == 32 else 4)
