@@ -44,7 +44,7 @@ extern "C" {
  *  53  descriptor hardening (0): 1 = every non-null pointer of a convolution / weight-gradient / combine / BatchNorm-backward / mask-add descriptor is checked with
  *      hipPointerGetAttributes before the launch (MFC_ERR_INVALID_ARG for host or unmapped addresses instead of a GPU fault); the -m gpu tests run with it on
  *  54  write-through (sc1) 16-byte output stores from this many MB of output per launch (12; 0 = plain stores everywhere): mfcnet-tracker_amd/csrc/common.h, mfc_st16
- *  55  conv: score weight (%) of the 8-wave geometries for launches that want the fused data-gradient epilogue (0: 4-wave forms; -1 = switch 19)
+ *  55  conv: score weight (%) of the 8-wave geometries for launches that want the fused data-gradient epilogue (90; 0: 4-wave forms; -1 = switch 19)
  *  56  lanes: in a program without detached records (the forward pass) lane 4 runs on the detached stream's hardware queue (1)
  *  57  ring kernel: thousands of pixels (N*H*W) from which a 64-channel data gradient takes the unfused ring launch + a reduce pass (100) */
 int mfc_set_flag(int id, int value);

@@ -675,9 +675,10 @@ int mfc_conv_set_grid(int v) { g_conv_grid = v > 0 ? v : 512; return 0; }
 
 static int g_conv_nw8 = 90;           // 8-wave (one workgroup per CU) geometries: score weight in % (0 = never; 90 sends ties to the 4-wave form); tuning: mfc_set_flag(19, pct)
 int mfc_conv_set_nw8(int v) { g_conv_nw8 = v; return 0; }
-int g_conv_nw8_fused = 0;             // the same weight for launches that ask for the fused data-gradient epilogue (MFC_CONV_WANT_FA); -1 = g_conv_nw8.  0: those launches
-                                      // use 4-wave geometries -- alone they are slower (conv_igemm 14.6 -> 15.5 ms per serial step) but two workgroups per CU hide each
-                                      // other's exposed epilogue reads and share the chip better with the lanes: step 36.78 -> 36.60 ms (twice); mfc_set_flag(55, pct)
+int g_conv_nw8_fused = 90;            // the same weight for launches that ask for the fused data-gradient epilogue (MFC_CONV_WANT_FA); -1 = g_conv_nw8, 0 = 4-wave geometries only.
+                                      // Measured twice in round 4: before the fuse stage had one join per module and the 64-channel data gradients moved to the ring
+                                      // launch, 4-wave geometries won (two workgroups per CU hide each other's exposed epilogue reads: 36.78 -> 36.60 ms); on the final
+                                      // structure the 8-wave ones do (701.4 / 704.6 -> 710.0 / 711.1 frames/s, same box, alternating); mfc_set_flag(55, pct)
 
 static bool conv_variant_fa(int dtype, int NT, int MT, int PM, int NW);
 
