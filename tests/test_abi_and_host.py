@@ -298,3 +298,35 @@ def test_every_planned_launch_reads_the_weight_image_that_was_packed_for_it(H, W
     assert n > 500
     # layer1's four conv2 data gradients (every width); W32 also the 32 conv2's of its 64-channel branch (N * H * W >= 100 000 pixels at both sizes)
     assert ring64 == (4 + 32 if width == 32 else 4)
+
+
+@pytest.mark.parametrize("width,basic,aux,one_join", [(32, False, False, True), (32, False, False, False), (48, False, False, True), (32, False, True, True), (32, True, True, True)],
+                         ids=["w32", "w32-round3-fuse-order", "w48", "w32-flow-depth", "w32-basic-flow-depth"])
+def test_lanes_of_the_planned_programs_are_race_free(width, basic, aux, one_join):
+    """tools/lane_hazards.py: inside a fork ... join section of a program only same-lane records are ordered.  From the descriptors of a dry plan:
+    no record of a section writes a tensor (base pointer + channel range) that a record on ANOTHER lane of the same section reads or writes, and
+    nothing after a detached record (weight gradient) writes what it reads.  Run for the benchmarked plans, both emission orders of the fuse stage,
+    and -- so that a checker that finds nothing is known to be able to find something -- for a plan whose one-join-per-module record is dropped."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lane_hazards as H
+    import mfcnet_amd as mfc
+    from mfcnet_amd import _lib as L
+    from mfcnet_amd import plan as P
+    cls = mfc.HRNetMultiBasic if basic else mfc.HRNetMultiLarge
+    m = cls(num_classes=5, num_frames=3, pretrained=False, width=width, compute_dtype="bf16", optflow_inputs=aux, depth_inputs=aux).train()
+    m.fuse_one_join = one_join
+    pl = P.Plan(m, 4, 480, 640, aux, aux, True, True, True, torch.device("cpu"), dry=True)
+    secs, hz = H.check_plan(pl, L)
+    assert len(secs["forward"]) >= 8 and len(secs["backward"]) >= 8
+    assert not hz, hz[:5]
+    if width == 32 and one_join and not aux:
+        orig = P.Plan.join
+        try:
+            def no_join(self):
+                self.cur_lane = 0
+                self.ops.append(("nojoin",))          # (no record: the fuse sums then share a section with the paths they read)
+            P.Plan.join = no_join
+            bad = P.Plan(m, 4, 480, 640, False, False, True, True, True, torch.device("cpu"), dry=True)
+            assert len(H.check_plan(bad, L)[1]) > 50
+        finally:
+            P.Plan.join = orig
