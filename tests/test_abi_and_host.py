@@ -330,3 +330,24 @@ def test_lanes_of_the_planned_programs_are_race_free(width, basic, aux, one_join
             assert len(H.check_plan(bad, L)[1]) > 50
         finally:
             P.Plan.join = orig
+
+
+def test_never_acc_promise_decides_the_launch_before_the_weights_are_packed():
+    """MFC_CONV_NEVER_ACC (include/mfcnet_hip.h): a 64-channel 3x3 data gradient that asks for a fusable launch gets conv_igemm's (fa = 1) -- unless it
+    promises never to accumulate AND the image is large, where the plain ring launch (no fusions, its own weight layout) is chosen.  The choice must be a
+    function of what is known when mfc_conv2d_layout is asked, i.e. it must not change when `accumulate` is filled in afterwards."""
+    from mfcnet_amd import _lib as L
+
+    def desc(flags, N=24, H=60, W=80, acc=0):
+        d = L.ConvDesc(16, 16, 16, 0, 0, 0, L.BF16, N, H, W, 64, 64, H, W, 64, 64, H, W, 3, 3, -1, -1, 1, 1, 1, 0, 0, 0, N // 3, acc, 0, 0)
+        d.flags = flags
+        return d
+    geo = lambda lay: (lay.fa, lay.NW, lay.MT, lay.TH, lay.TW, lay.grid) + tuple(sorted(L.pack_job_fields(lay).items()))
+    ring = L.conv_layout(desc(L.CONV_WANT_FA | L.CONV_NEVER_ACC))
+    assert (ring.fa, ring.NW, ring.TH, ring.TW, ring.nchunks) == (0, 4, 8, 16, 1)                # the ring launch: 8 x 16 tiles, all weights resident, no fusions offered
+    fused = L.conv_layout(desc(L.CONV_WANT_FA))
+    assert fused.fa == 1 and geo(fused) != geo(ring)                                             # conv_igemm's fusable launch
+    later = L.conv_layout(desc(L.CONV_WANT_FA, acc=1))                                           # (what the planner fills in after packing)
+    assert geo(later) == geo(fused)
+    small = L.conv_layout(desc(L.CONV_WANT_FA | L.CONV_NEVER_ACC, N=3))                          # 14 400 pixels: below the threshold
+    assert small.fa == 1
