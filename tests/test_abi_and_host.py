@@ -351,3 +351,75 @@ def test_never_acc_promise_decides_the_launch_before_the_weights_are_packed():
     assert geo(later) == geo(fused)
     small = L.conv_layout(desc(L.CONV_WANT_FA | L.CONV_NEVER_ACC, N=3))                          # 14 400 pixels: below the threshold
     assert small.fa == 1
+
+
+def test_launch_choice_never_depends_on_fields_the_planner_fills_in_later():
+    """Property check of mfc_conv2d_layout over every residual-block shape and 400 pseudo-random data-gradient descriptors (1x1 / 3x3, stride 1 and the stride-2 forms, 16-bit, channel
+    counts of HRNet-W32 / W48 / the head, image sizes from 15x20 to 120x160, with and without MFC_CONV_WANT_FA / MFC_CONV_NEVER_ACC): the packed
+    weight layout of the launch chosen for the descriptor as the planner first asks about it must be that of the launch chosen after `accumulate`, and -- where fa = 1 was
+    reported -- `acc_src`, `bn_y` / `out_stats` have been filled in.  (The kernel families dispatch on eligibility predicates; one that looked at
+    such a field would make a launch read weights packed for another kernel.)"""
+    import random
+    from mfcnet_amd import _lib as L
+    rnd = random.Random(1234)
+    chans = [5, 15, 16, 32, 48, 64, 96, 128, 192, 256, 384, 480]
+    sizes = [(15, 20), (30, 40), (60, 80), (120, 160), (17, 23)]
+    # what must not move: the packed weight image (its blocking and size); and a launch that was offered the fusions must still take them
+    geo = lambda lay: (lay.bytes,) + tuple(sorted(L.pack_job_fields(lay).items()))
+    checked = fusable = 0
+    # every residual-block shape (equal channels, 3x3 / stride 1: the ring kernel's territory) explicitly, then 400 random ones
+    fixed = [(c, c, hw, n, 3, "s1", fl) for c in chans for hw in sizes for n in (3, 24) for fl in (0, L.CONV_WANT_FA, L.CONV_WANT_FA | L.CONV_NEVER_ACC)]
+    for it in range(len(fixed) + 400):
+        if it < len(fixed):
+            cin, cout, (H, W), N, k, form, fixed_flags = fixed[it]
+        else:
+            fixed_flags = None
+            cin, cout = rnd.choice(chans), rnd.choice(chans)
+            H, W = rnd.choice(sizes)
+            N = rnd.choice([3, 6, 12, 24])
+            k = rnd.choice([1, 3])
+            form = rnd.choice(["s1", "s1", "s2_class", "s2_all"]) if k == 3 else "s1"
+        cinp, coutp = -(-cin // 8) * 8, -(-cout // 8) * 8
+        pad = k // 2
+        if form == "s1":
+            args = (N, H, W, cinp, cin, H, W, coutp, cout, H, W, k, k, -(k - 1 - pad), -(k - 1 - pad), 1, 1, 1, 0, 0)
+        elif form == "s2_all":
+            Ho, Wo = 2 * H, 2 * W
+            args = (N, H, W, cinp, cin, Ho, Wo, coutp, cout, (Ho + 1) // 2, (Wo + 1) // 2, 2, 2, 0, 0, 1, 2, 2, 0, 0)
+        else:
+            Ho, Wo = 2 * H, 2 * W
+            ph, pw = rnd.randrange(2), rnd.randrange(2)
+            ta = 2 if ph == 1 else 1
+            tb = 2 if pw == 1 else 1
+            args = (N, H, W, cinp, cin, Ho, Wo, coutp, cout, (Ho - ph + 1) // 2, (Wo - pw + 1) // 2, ta, tb, 0, 0, 1, 2, 2, ph, pw)
+        flags = rnd.choice([0, L.CONV_WANT_FA, L.CONV_WANT_FA, L.CONV_WANT_FA | L.CONV_NEVER_ACC]) | (L.CONV_S2_CLASSES if form == "s2_all" else 0)
+        if fixed_flags is not None:
+            flags = fixed_flags
+
+        def make(**kw):
+            d = L.ConvDesc(16, 16, 16, 0, 0, 0, L.BF16, *args, 0, N // 3, 0, 0, 0)
+            d.flags = flags
+            for key, val in kw.items():
+                setattr(d, key, val)
+            return d
+        try:
+            base = L.conv_layout(make())
+        except L.MfcError:
+            continue
+        checked += 1
+        variants = []
+        if not (flags & L.CONV_NEVER_ACC):
+            variants.append(dict(accumulate=1))
+        if base.fa == 1:
+            fusable += 1
+            variants.append(dict(bn_y=16, bn_coef=16, out_stats=16, bn_mask_mode=2))
+            variants.append(dict(bn_y=16, bn_coef=16, out_stats=16, bn_mask_mode=3, bn_bits=16))
+            if not (flags & L.CONV_NEVER_ACC):
+                variants.append(dict(accumulate=1, acc_src=16))
+                variants.append(dict(accumulate=1, acc_src=16, bn_y=16, bn_coef=16, out_stats=16, bn_mask_mode=3, bn_bits=16))
+        for kw in variants:
+            lay = L.conv_layout(make(**kw))
+            assert geo(lay) == geo(base), (cin, cout, k, form, H, W, N, flags, kw)
+            if kw.get("bn_y") or kw.get("acc_src"):
+                assert lay.fa == 1, (cin, cout, k, form, H, W, N, flags, kw)
+    assert checked > 600 and fusable > 150, (checked, fusable)
