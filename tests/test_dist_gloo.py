@@ -217,3 +217,31 @@ def test_reduce_scatter_sharded_update_all_gather_equals_allreduce():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_shard_bounds_tile_the_arena_for_every_world_size():
+    """dist.shard_bounds (ShardedStep: reduce-scatter + sharded Adam + all-gather): for 1 ... 8 ranks and arena sizes that are not multiples of anything,
+    the shards are contiguous, cover [0, n) exactly once, every interior boundary is a multiple of 4 elements (the Adam kernel's float4 granules never
+    straddle two ranks), all but the last non-empty shard have the same size (what reduce_scatter / all_gather of equal chunks need), and the real arenas
+    (W32: 41.1 M, W48: 66.1 M parameters) split evenly to within one granule."""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "mfcnet-tracker_amd"))
+    from mfcnet_amd.dist import shard_bounds
+    rnd = random.Random(7)
+    sizes = [1, 3, 4, 5, 17, 1023, 41_139_221, 66_104_869] + [rnd.randrange(1, 10_000_000) for _ in range(50)]
+    for n in sizes:
+        for world in range(1, 9):
+            b = shard_bounds(n, world)
+            assert len(b) == world and b[0][0] == 0 and b[-1][1] == n
+            for r in range(world):
+                lo, hi = b[r]
+                assert 0 <= lo <= hi <= n
+                if r:
+                    assert lo == b[r - 1][1]
+                if hi < n:
+                    assert hi % 4 == 0
+            full = [hi - lo for lo, hi in b if hi < n]
+            assert len(set(full)) <= 1
+            if n > 64 * world:
+                per = -(-n // world)
+                assert max(hi - lo for lo, hi in b) - per < 4
